@@ -1,0 +1,233 @@
+"""Generate golden fixtures by running the REAL reference (/root/reference, CPU, bf16) on seeded inputs.
+
+Build-container only (the reference never travels to the GPU box).  Usage:
+    python tests/golden/make_golden.py [dit] [chunk] [sched] [vae]
+Writes tests/golden/*.pt.  Inputs are regenerated from seeds by the tests (mmpl_amd.synthetic), so the
+fixtures hold expected OUTPUTS of the reference (full or strided + sha256), plus known-answer scalars.
+While generating, the oracle restatement (oracle/) is run on the same inputs and its agreement with the
+reference is printed -- tests/test_oracle_golden.py re-checks that against the committed files.
+"""
+import hashlib
+import os
+import sys
+import time
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from _ref_import import load_reference  # noqa: E402
+from mmpl_amd.synthetic import WAN_CONFIGS, dit_state_dict, philox_normal  # noqa: E402
+from oracle import stage_ref, unipc_ref  # noqa: E402
+from oracle import wan_dit_ref as W  # noqa: E402
+
+torch.set_grad_enabled(False)
+S480 = 1560
+H, Wd = 60, 104
+
+
+def sha(t: torch.Tensor) -> str:
+    return hashlib.sha256(t.contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()
+
+
+def rel_l2(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+def build_ref_model(fps, cfg_name="tiny", seed=1):
+    cfg = WAN_CONFIGS[cfg_name]
+    m = fps.CausalFPSWanModel(model_type="t2v", dim=cfg["dim"], ffn_dim=cfg["ffn_dim"], num_heads=cfg["num_heads"],
+                              num_layers=cfg["num_layers"], text_dim=cfg["text_dim"], freq_dim=cfg["freq_dim"]).eval()
+    sd = dit_state_dict(cfg, seed=seed)
+    missing = m.load_state_dict(sd, strict=True)
+    m = m.to(torch.bfloat16)
+    return m, sd, cfg
+
+
+def ref_caches(cfg, n_slots=15):
+    kv = [{"k": torch.zeros(1, n_slots * S480, cfg["num_heads"], 128, dtype=torch.bfloat16),
+           "v": torch.zeros(1, n_slots * S480, cfg["num_heads"], 128, dtype=torch.bfloat16),
+           "global_end_index": torch.tensor([0]), "local_end_index": torch.tensor([0]),
+           "attention_vis_index": []} for _ in range(cfg["num_layers"])]
+    cross = [{"k": None, "v": None, "is_init": False} for _ in range(cfg["num_layers"])]
+    return kv, cross
+
+
+def ref_forward(m, x, tval, ctx, kv, cross, frames):
+    """x: [1, nF, 16, h, w] (pipeline layout) -> flow [1, nF, 16, h, w]; mirrors WanFPSWrapper.forward."""
+    t = torch.full([1, len(frames)], float(tval), dtype=torch.float32)
+    y = m(x.permute(0, 2, 1, 3, 4), t=t, context=ctx, seq_len=32760, kv_cache=kv, crossattn_cache=cross,
+          current_start=[f * S480 for f in frames], cache_start=[f * S480 for f in frames])
+    return y.permute(0, 2, 1, 3, 4)
+
+
+def make_context(cfg, seed, n_valid=48):
+    c = philox_normal([1, 512, cfg["text_dim"]], seed)
+    c[:, n_valid:] = 0                                # pad-zeroing, wan_wrapper.py:46-47
+    return c
+
+
+def gen_dit():
+    fps, *_ = load_reference()
+    m, sd, cfg = build_ref_model(fps, "tiny", seed=1)
+    ocfg = W.DitCfg(**cfg)
+    ctx = make_context(cfg, 11)
+    noise = philox_normal([1, 21, 16, H, Wd], 7)
+    kv, cross = ref_caches(cfg)
+    okv = W.new_kv_cache(ocfg, 15, S480)
+    ocross = [None] * cfg["num_layers"]
+    vis = stage_ref.VisIndex()
+    out = {}
+    stages = stage_ref.stage_frames(stage_ref.T2V_CLEAN_STEPS)
+    for si, frames in enumerate(stages):
+        if si == 2:
+            for blk in kv:
+                for v in (31200, 29640):
+                    if v in blk["attention_vis_index"]:
+                        blk["attention_vis_index"].remove(v)
+            vis.hide()
+        if si == 3:
+            for blk in kv:
+                for v in (31200, 29640):
+                    if v not in blk["attention_vis_index"]:
+                        blk["attention_vis_index"].append(v)
+            vis.show()
+        x = noise[:, frames]
+        tval = [999.0, 700.0, 301.0, 0.0][si]
+        t0 = time.time()
+        y = ref_forward(m, x, tval, ctx, kv, cross, frames)
+        dt = time.time() - t0
+        vis.on_forward(frames)
+        # the reference gathers K/V in `list(set(...))` order (causal_fps_model.py:219); record it so the
+        # oracle can be pinned bit-exactly (attention is permutation-invariant only up to fp32 summation order)
+        ref_order = [stage_ref.slot_of(v // S480) for v in kv[0]["attention_vis_index"]]
+        assert sorted(ref_order) == sorted(vis.slots()), (ref_order, vis.slots())
+        out[f"s{si}_vis_order"] = ref_order
+        t = torch.full([1, len(frames)], tval, dtype=torch.float32)
+        yo = W.dit_forward(sd, ocfg, x[0].permute(1, 0, 2, 3), t, ctx[0], okv, ocross, frames,
+                           stage_ref.write_slots_for(frames), ref_order).permute(1, 0, 2, 3).unsqueeze(0)
+        print(f"[dit] stage {si} frames {frames} ref {dt:.2f}s  oracle-vs-ref rel_l2={rel_l2(yo, y):.3e} "
+              f"max|d|={(yo.float() - y.float()).abs().max().item():.3e} rms={y.float().pow(2).mean().sqrt().item():.3f}")
+        out[f"s{si}_sha"] = sha(y)
+        out[f"s{si}_strided"] = y[..., ::2, ::2].clone()
+        if si == 0:
+            out["s0_full"] = y.clone()
+    # cache content pin: K/V of layer 1, slot 13 (frame 19) strided
+    out["kv_l1_slot13_k"] = kv[1]["k"][0, 13 * S480:14 * S480:13].clone()
+    out["kv_l1_slot13_v"] = kv[1]["v"][0, 13 * S480:14 * S480:13].clone()
+    ok = torch.equal(okv[1]["k"][0, 13 * S480:14 * S480:13], out["kv_l1_slot13_k"])
+    print("[dit] oracle cache slot13 K equal to reference:", ok)
+    out["meta"] = dict(cfg="tiny", weight_seed=1, ctx_seed=11, noise_seed=7, n_valid=48, tvals=[999.0, 700.0, 301.0, 0.0])
+    torch.save(out, os.path.join(HERE, "dit_forward_tiny.pt"))
+
+
+def gen_chunk(steps=2):
+    """Re-enact casual_fps_inference.py:250-403 with the reference model + reference UniPC (steps reduced)."""
+    fps, _, _, _, unipc, sched = load_reference()
+    m, sd, cfg = build_ref_model(fps, "tiny", seed=2)
+    ocfg = W.DitCfg(**cfg)
+    ctx_c, ctx_u = make_context(cfg, 21, 40), make_context(cfg, 22, 12)
+    noise = philox_normal([1, 21, 16, H, Wd], 23)
+    renoise = {f: philox_normal([1, 16, H, Wd], 100 + f) for f in (4, 9, 13, 18)}
+    kvs = [ref_caches(cfg), ref_caches(cfg)]
+    ctxs = [ctx_c, ctx_u]
+    stages = stage_ref.stage_frames(stage_ref.T2V_CLEAN_STEPS)
+    output = torch.zeros_like(noise)
+    handoff = None
+    fm = sched.FlowMatchScheduler(shift=5.0, sigma_min=0.0, extra_one_step=True)
+    fm.set_timesteps(1000, training=True)
+    ddmp_t = torch.tensor([[1980.0]])                  # timesteps[idx]+1000 >= 1000 for any idx (pipeline :96-107)
+    t0 = time.time()
+    for si, frames in enumerate(stages):
+        latents = noise[:, frames]
+        if si in (2, 3):
+            src = (3, 10) if si == 2 else (12, 19)
+            latents[:, 0:1] = fm.add_noise(output[:, src[0]:src[0] + 1].flatten(0, 1), renoise[frames[0]],
+                                           ddmp_t.flatten(0, 1)).unflatten(0, (1, 1))
+            latents[:, -1:] = fm.add_noise(output[:, src[1]:src[1] + 1].flatten(0, 1), renoise[frames[-1]],
+                                           ddmp_t.flatten(0, 1)).unflatten(0, (1, 1))
+            for kv, _ in kvs:
+                for blk in kv:
+                    for v in (31200, 29640):
+                        if si == 2 and v in blk["attention_vis_index"]:
+                            blk["attention_vis_index"].remove(v)
+                        if si == 3 and v not in blk["attention_vis_index"]:
+                            blk["attention_vis_index"].append(v)
+        s = unipc.FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+        s.set_timesteps(steps, device="cpu", shift=5.0)
+        for t in s.timesteps:
+            fc = ref_forward(m, latents, t, ctxs[0], kvs[0][0], kvs[0][1], frames)
+            fu = ref_forward(m, latents, t, ctxs[1], kvs[1][0], kvs[1][1], frames)
+            flow = fu + 5.0 * (fc - fu)
+            latents = s.step(flow, t, latents, return_dict=False)[0]
+        output[:, frames] = latents
+        if si == 1:
+            handoff = torch.cat([output[:, :1], latents], dim=1)
+        for w in (0, 1):
+            ref_forward(m, latents, 0.0, ctxs[w], kvs[w][0], kvs[w][1], frames)
+    print(f"[chunk] reference stage loop ({steps} steps/stage): {time.time() - t0:.1f}s")
+    t0 = time.time()
+    o_out, o_hand, _ = stage_ref.run_chunk(sd, ocfg, noise, ctx_c[0], ctx_u[0], renoise, None, "t2v", 5.0, steps, 5.0)
+    print(f"[chunk] oracle stage loop: {time.time() - t0:.1f}s  rel_l2 vs ref: out={rel_l2(o_out, output):.3e} "
+          f"handoff={rel_l2(o_hand, handoff):.3e}  out rms={output.float().pow(2).mean().sqrt().item():.3f}")
+    torch.save(dict(out_sha=sha(output), out_strided=output[..., ::2, ::2].clone(), handoff_sha=sha(handoff),
+                    handoff_strided=handoff[..., ::3, ::3].clone(),
+                    meta=dict(cfg="tiny", weight_seed=2, ctx_seeds=(21, 22), n_valid=(40, 12), noise_seed=23,
+                              renoise_seed_base=100, steps=steps, guidance=5.0, shift=5.0)),
+               os.path.join(HERE, "chunk_t2v_tiny.pt"))
+
+
+def gen_sched():
+    _, _, _, _, unipc, sched = load_reference()
+    s = unipc.FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+    s.set_timesteps(50, device="cpu", shift=5.0)
+    o = unipc_ref.FlowUniPCRef(1000, 2, 1.0)
+    o.set_timesteps(50, shift=5.0)
+    assert torch.equal(s.timesteps, o.timesteps) and torch.equal(s.sigmas, o.sigmas)
+    out = dict(timesteps=s.timesteps.clone(), sigmas=s.sigmas.clone())
+    # toy velocity field trajectory in bf16 (what the pipeline feeds) and fp32
+    for dt, name in ((torch.bfloat16, "bf16"), (torch.float32, "f32")):
+        x = philox_normal([1, 3, 4, 6, 8], 5, dt)
+        target = philox_normal([1, 3, 4, 6, 8], 6, dt)
+        s = unipc.FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+        s.set_timesteps(50, device="cpu", shift=5.0)
+        o = unipc_ref.FlowUniPCRef(1000, 2, 1.0)
+        o.set_timesteps(50, shift=5.0)
+        xr, xo = x.clone(), x.clone()
+        traj = []
+        for i, t in enumerate(s.timesteps):
+            vr = (xr - target) * (1.0 + 0.1 * torch.sin(xr.float() * 3 + i).to(dt))
+            xr = s.step(vr, t, xr, return_dict=False)[0]
+            vo = (xo - target) * (1.0 + 0.1 * torch.sin(xo.float() * 3 + i).to(dt))
+            xo = o.step(vo, xo)
+            traj.append(xr.clone())
+        print(f"[sched] {name}: oracle-vs-ref max|d| = {(xo.float() - xr.float()).abs().max().item():.3e}")
+        out[f"traj_{name}"] = torch.stack(traj)
+    fm = sched.FlowMatchScheduler(shift=5.0, sigma_min=0.0, extra_one_step=True)
+    fm.set_timesteps(1000, training=True)
+    of = unipc_ref.FlowMatchRef(5.0, 1000)
+    assert torch.equal(fm.timesteps, of.timesteps)
+    out["fm_timesteps_sample"] = fm.timesteps[[0, 980, 999]].clone()
+    a, n = philox_normal([2, 4, 3, 5], 1, torch.bfloat16), philox_normal([2, 4, 3, 5], 2, torch.bfloat16)
+    out["fm_add_noise_1980"] = fm.add_noise(a, n, torch.tensor([1980.0, 1000.0]))
+    out["fm_add_noise_mid"] = fm.add_noise(a, n, torch.tensor([500.0, 92.59]))
+    assert torch.equal(out["fm_add_noise_1980"], n)
+    assert torch.equal(of.add_noise(a, n, torch.tensor([500.0, 92.59])), out["fm_add_noise_mid"])
+    torch.save(out, os.path.join(HERE, "sched.pt"))
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["dit", "chunk", "sched", "vae"]
+    if "sched" in what:
+        gen_sched()
+    if "dit" in what:
+        gen_dit()
+    if "chunk" in what:
+        gen_chunk()
+    if "vae" in what:
+        from make_golden_vae import gen_vae
+        gen_vae()
