@@ -1,0 +1,106 @@
+/* libmmpl_hip.so -- C ABI of the MI355X-native MMPL denoising hot path.
+ *
+ * The reference (Tele-AI/MMPL) has no FFI: its seams are Python signatures.  Each entry point
+ * below names the reference interface it replaces (paths relative to the reference root); the Python mirror
+ * in mmpl_amd/ binds them with ctypes (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions: every pointer marked "dev" is a borrowed device pointer (e.g. torch.Tensor.data_ptr()); nothing
+ * is retained after the call returns except by mmpl_dit_bind_weights (which stores the weight pointers) and
+ * nothing is allocated on the device except two 256 KiB RoPE tables owned by the handle.  All tensors are
+ * bfloat16 unless stated.  Every call takes the HIP stream to enqueue on and is asynchronous with respect to
+ * the host.  Return value: 0 = ok, non-zero = error (text via mmpl_last_error(), thread-local).
+ */
+#ifndef MMPL_HIP_H
+#define MMPL_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mmpl_stream_t; /* hipStream_t */
+
+typedef struct MmplDitConfig {
+  int dim, ffn_dim, num_heads, num_layers; /* wan/configs/wan_t2v_14B.py:17-25 */
+  int text_dim, freq_dim, in_dim, out_dim, text_len;
+  float eps;
+  int lat_h, lat_w;   /* latent frame size: 60x104 (480p, the reference's literal 1560 tokens) or 90x160 (720p) */
+  int max_frames;     /* largest stage (7) */
+} MmplDitConfig;
+
+typedef struct MmplDit MmplDit;
+
+/* Number of weight pointers mmpl_dit_bind_weights expects, and the name of slot i (reference state_dict key,
+ * "blocks.N." prefix for per-layer slots; packed slots say how they are packed). */
+int mmpl_dit_num_weights(const MmplDitConfig* cfg);
+const char* mmpl_dit_weight_name(int slot_in_layer_or_global, int per_layer);
+
+/* CausalFPSWanModel.__init__ (wan/modules/causal_fps_model.py:409-530): geometry + RoPE tables. */
+int mmpl_dit_create(const MmplDitConfig* cfg, MmplDit** out);
+void mmpl_dit_destroy(MmplDit* h);
+/* load_state_dict seam (Wan_fps_inference_1gpu.py:66-68): stores n borrowed dev pointers, order = weight slots. */
+int mmpl_dit_bind_weights(MmplDit* h, const void* const* dev_ptrs, int n);
+
+size_t mmpl_dit_workspace_bytes(const MmplDit* h, int n_frames);
+size_t mmpl_dit_context_workspace_bytes(const MmplDit* h);
+
+/* text_embedding + per-layer cross-attn K/V (causal_fps_model.py:780-786, model.py:175-180), once per prompt.
+ * context: dev [text_len, text_dim] zero-padded; cross_k/cross_v: dev out [num_layers, text_len, dim]. */
+int mmpl_dit_precompute_context(MmplDit* h, const void* context, void* cross_k, void* cross_v, void* workspace,
+                                size_t workspace_bytes, mmpl_stream_t stream);
+
+/* CausalFPSWanModel._forward_inference (causal_fps_model.py:708-837) behind WanFPSWrapper.forward
+ * (utils/wan_wrapper.py:422-493).
+ *   x_in / out : dev [n_frames, 16, lat_h, lat_w]  (the pipeline's [B=1, F, C, H, W] layout)
+ *   t_dev      : dev float32 [n_frames]
+ *   frame_ids  : host, RoPE temporal index per frame (= current_start / frame_seqlen)
+ *   write_slots: host, KV slot each frame's K/V is written to before attending; all -1 = do not persist
+ *                (the reference's [13..18] stage, causal_fps_model.py:254-264)
+ *   visible_slots: host, cache slots attended (attention_vis_index after the 19,20 -> 13,14 remap)
+ *   k_cache / v_cache: dev [num_layers, n_slots * S, dim], mutated in place like the reference's kv_cache
+ *   cross_k / cross_v: from mmpl_dit_precompute_context */
+int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int n_frames, const int* frame_ids,
+                     const int* write_slots, const int* visible_slots, int n_visible, void* k_cache, void* v_cache,
+                     int n_slots, const void* cross_k, const void* cross_v, void* out, void* workspace,
+                     size_t workspace_bytes, mmpl_stream_t stream);
+
+/* attention() seam (wan/modules/attention.py:139-185) over paged K/V.  q/o: row r, head h at base + r*ld + h*128.
+ * k_pages/v_pages: host arrays of n_pages dev pointers, each page = page_rows rows of stride ldk/ldv. */
+int mmpl_attn_fwd(const void* q, int ldq, void* o, int ldo, const void* const* k_pages, const void* const* v_pages,
+                  int ldk, int ldv, int n_pages, int page_rows, int Lq, int num_heads, float softmax_scale,
+                  mmpl_stream_t stream);
+
+/* nn.Linear (+ fused epilogue). epi: 0 bias, 1 bias+GELU(tanh), 2 bias+SiLU, 3 x + (y*gate[frame]) , 4 x + y */
+int mmpl_gemm(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N, int K,
+              int epi, const void* res, int ldres, const void* gate, int gate_frame_stride, int rows_per_frame,
+              mmpl_stream_t stream);
+
+/* WanLayerNorm (+ per-frame modulation or affine) (wan/modules/model.py:89-99, causal_fps_model.py:343,352,355) */
+int mmpl_layernorm(const void* x, int ldx, void* y, int ldy, int rows, int d, float eps, const void* scale,
+                   const void* shift, int mod_frame_stride, int rows_per_frame, const void* w, const void* b,
+                   mmpl_stream_t stream);
+
+/* WanRMSNorm over the full dim on q (in place) and k, causal_fps_rope_apply, KV slot write
+ * (model.py:70-86, causal_fps_model.py:27-55, 211-217).  k_dst/v_dst: host arrays of n_frames dev page pointers. */
+int mmpl_qknorm_rope(MmplDit* h, void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* wq,
+                     const void* wk, int n_frames, const int* frame_ids, void* const* k_dst, void* const* v_dst,
+                     mmpl_stream_t stream);
+
+/* CFG combine + FlowUniPCMultistepScheduler.step (casual_fps_inference.py:366-374, fm_solvers_unipc.py:655-739) */
+typedef struct MmplUniPCStep {
+  float guidance, sigma_cur;
+  int use_corrector, corr_order;
+  float c_c1, c_c2, c_c3, c_inv_rk, c_rho0, c_rho_last;
+  int pred_order;
+  float p_c1, p_c2, p_c3, p_inv_rk;
+} MmplUniPCStep;
+int mmpl_cfg_unipc_step(const void* flow_cond, const void* flow_uncond, void* x, void* m0, void* m1, void* last_sample,
+                        size_t n, const MmplUniPCStep* s, mmpl_stream_t stream);
+
+const char* mmpl_last_error(void);
+const char* mmpl_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,372 @@
+// C ABI of libmmpl_hip.so (see include/mmpl_hip.h) and the host-side orchestration of one Wan DiT forward.
+// The forward is a fixed sequence of kernel launches on the caller's stream with no host synchronisation and
+// no allocation, so it is hipGraph-capturable per (stage, pass) shape.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mmpl_hip.h"
+#include "kernels.h"
+
+static thread_local std::string g_err;
+static int fail(const char* where, const char* what) {
+  g_err = std::string(where) + ": " + what;
+  return 1;
+}
+#define HIP_TRY(expr, where)                                     \
+  do {                                                           \
+    hipError_t e__ = (expr);                                     \
+    if (e__ != hipSuccess) return fail(where, hipGetErrorString(e__)); \
+  } while (0)
+
+enum {  // global weight slots
+  G_PE_W, G_PE_B, G_TXT0_W, G_TXT0_B, G_TXT2_W, G_TXT2_B, G_TE0_W, G_TE0_B, G_TE2_W, G_TE2_B, G_TP_W, G_TP_B,
+  G_HEAD_MOD, G_HEAD_W, G_HEAD_B, G_BLOCK_MOD, NG
+};
+enum {  // per-layer weight slots
+  L_QKV_W, L_QKV_B, L_NQ, L_NK, L_O_W, L_O_B, L_N3_W, L_N3_B, L_CQ_W, L_CQ_B, L_CNQ, L_CK_W, L_CK_B, L_CNK, L_CV_W,
+  L_CV_B, L_CO_W, L_CO_B, L_F0_W, L_F0_B, L_F2_W, L_F2_B, NL
+};
+static const char* kGlobalNames[NG] = {
+    "patch_embedding.weight", "patch_embedding.bias", "text_embedding.0.weight", "text_embedding.0.bias",
+    "text_embedding.2.weight", "text_embedding.2.bias", "time_embedding.0.weight", "time_embedding.0.bias",
+    "time_embedding.2.weight", "time_embedding.2.bias", "time_projection.1.weight", "time_projection.1.bias",
+    "head.modulation", "head.head.weight", "head.head.bias", "pack:blocks.*.modulation[L,6,dim]"};
+static const char* kLayerNames[NL] = {
+    "pack:self_attn.{q,k,v}.weight[3dim,dim]", "pack:self_attn.{q,k,v}.bias[3dim]", "self_attn.norm_q.weight",
+    "self_attn.norm_k.weight", "self_attn.o.weight", "self_attn.o.bias", "norm3.weight", "norm3.bias",
+    "cross_attn.q.weight", "cross_attn.q.bias", "cross_attn.norm_q.weight", "cross_attn.k.weight", "cross_attn.k.bias",
+    "cross_attn.norm_k.weight", "cross_attn.v.weight", "cross_attn.v.bias", "cross_attn.o.weight", "cross_attn.o.bias",
+    "ffn.0.weight", "ffn.0.bias", "ffn.2.weight", "ffn.2.bias"};
+
+struct MmplDit {
+  MmplDitConfig cfg;
+  int S, gh, gw;
+  float* cos_tab = nullptr;  // [1024][64]
+  float* sin_tab = nullptr;
+  std::vector<const bf16_t*> w;
+  const bf16_t* G(int i) const { return w[i]; }
+  const bf16_t* Lw(int l, int i) const { return w[NG + l * NL + i]; }
+};
+
+extern "C" {
+
+const char* mmpl_last_error(void) { return g_err.c_str(); }
+const char* mmpl_version(void) { return "mmpl_hip 0.1 (gfx950)"; }
+int mmpl_dit_num_weights(const MmplDitConfig* cfg) { return NG + cfg->num_layers * NL; }
+const char* mmpl_dit_weight_name(int slot, int per_layer) {
+  if (per_layer) return (slot >= 0 && slot < NL) ? kLayerNames[slot] : nullptr;
+  return (slot >= 0 && slot < NG) ? kGlobalNames[slot] : nullptr;
+}
+
+int mmpl_dit_create(const MmplDitConfig* cfg, MmplDit** out) {
+  if (!cfg || !out) return fail("mmpl_dit_create", "null argument");
+  if (cfg->dim % cfg->num_heads || cfg->dim / cfg->num_heads != 128)
+    return fail("mmpl_dit_create", "head_dim must be 128 (both Wan2.1 models)");
+  if (cfg->dim > 5120 || cfg->dim % 128 || cfg->ffn_dim % 64 || cfg->text_dim % 64 || cfg->freq_dim % 64)
+    return fail("mmpl_dit_create", "unsupported dims");
+  if (cfg->lat_h % 2 || cfg->lat_w % 2 || cfg->max_frames < 1 || cfg->max_frames > 8 || cfg->in_dim != 16 || cfg->out_dim != 16)
+    return fail("mmpl_dit_create", "unsupported geometry");
+  MmplDit* h = new MmplDit();
+  h->cfg = *cfg;
+  h->gh = cfg->lat_h / 2;
+  h->gw = cfg->lat_w / 2;
+  h->S = h->gh * h->gw;
+  // RoPE tables: rope_params(1024, d - 4*(d//6)) | (1024, 2*(d//6)) x2, theta 1e4, fp64 (model.py:29-36,
+  // causal_fps_model.py:510-516), stored as fp32 cos / sin.
+  const int d = 128, dims[3] = {d - 4 * (d / 6), 2 * (d / 6), 2 * (d / 6)};
+  std::vector<float> c(1024 * 64), s(1024 * 64);
+  for (int pos = 0; pos < 1024; ++pos) {
+    int p = 0;
+    for (int part = 0; part < 3; ++part)
+      for (int j = 0; j < dims[part] / 2; ++j, ++p) {
+        const double freq = 1.0 / pow(10000.0, (double)(2 * j) / (double)dims[part]);
+        const double ang = (double)pos * freq;
+        c[pos * 64 + p] = (float)cos(ang);
+        s[pos * 64 + p] = (float)sin(ang);
+      }
+  }
+  if (hipMalloc(&h->cos_tab, c.size() * 4) != hipSuccess || hipMalloc(&h->sin_tab, s.size() * 4) != hipSuccess) {
+    delete h;
+    return fail("mmpl_dit_create", "hipMalloc of RoPE tables failed (is a GPU present?)");
+  }
+  hipMemcpy(h->cos_tab, c.data(), c.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(h->sin_tab, s.data(), s.size() * 4, hipMemcpyHostToDevice);
+  *out = h;
+  return 0;
+}
+
+void mmpl_dit_destroy(MmplDit* h) {
+  if (!h) return;
+  if (h->cos_tab) hipFree(h->cos_tab);
+  if (h->sin_tab) hipFree(h->sin_tab);
+  delete h;
+}
+
+int mmpl_dit_bind_weights(MmplDit* h, const void* const* ptrs, int n) {
+  if (!h || !ptrs) return fail("mmpl_dit_bind_weights", "null argument");
+  if (n != NG + h->cfg.num_layers * NL) return fail("mmpl_dit_bind_weights", "wrong pointer count");
+  h->w.resize(n);
+  for (int i = 0; i < n; ++i) {
+    if (!ptrs[i]) return fail("mmpl_dit_bind_weights", "null weight pointer");
+    h->w[i] = (const bf16_t*)ptrs[i];
+  }
+  return 0;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ workspace
+namespace {
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* b) : base((char*)b) {}
+  bf16_t* take(size_t elems) {
+    bf16_t* p = (bf16_t*)(base + off);
+    off += (elems * 2 + 255) & ~(size_t)255;
+    return p;
+  }
+};
+struct FwdWs {
+  bf16_t *x, *xn, *big, *attn, *ksc, *vsc, *patch, *sinu, *t1, *e, *se, *e0, *emod, *emod_head, *yh;
+  size_t bytes;
+};
+FwdWs carve_fwd(const MmplDit* h, int nF, void* base) {
+  const MmplDitConfig& c = h->cfg;
+  const size_t Lq = (size_t)nF * h->S, d = c.dim;
+  const size_t bigw = (size_t)(3 * c.dim > c.ffn_dim ? 3 * c.dim : c.ffn_dim);
+  Carver k(base);
+  FwdWs w;
+  w.x = k.take(Lq * d);
+  w.xn = k.take(Lq * d);
+  w.big = k.take(Lq * bigw);
+  w.attn = k.take(Lq * d);
+  w.ksc = k.take(Lq * d);
+  w.vsc = k.take(Lq * d);
+  w.patch = k.take(Lq * 64);
+  w.sinu = k.take((size_t)nF * c.freq_dim);
+  w.t1 = k.take((size_t)nF * d);
+  w.e = k.take((size_t)nF * d);
+  w.se = k.take((size_t)nF * d);
+  w.e0 = k.take((size_t)nF * 6 * d);
+  w.emod = k.take((size_t)c.num_layers * nF * 6 * d);
+  w.emod_head = k.take((size_t)nF * 2 * d);
+  w.yh = k.take(Lq * 64);
+  w.bytes = k.off;
+  return w;
+}
+
+int gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, bf16_t* C, int ldc, int M, int N, int K,
+         int epi, const bf16_t* res, int ldres, const bf16_t* gate, int gfs, int rpf, hipStream_t s) {
+  GemmArgs g{A, lda, W, ldw, bias, C, ldc, M, N, K, epi, res, ldres, gate, gfs, rpf > 0 ? rpf : 1};
+  hipError_t e = mmpl_launch_gemm(g, s);
+  if (e != hipSuccess) return fail("gemm", hipGetErrorString(e));
+  return 0;
+}
+#define TRY(x) do { if ((x) != 0) return 1; } while (0)
+}  // namespace
+
+extern "C" {
+
+size_t mmpl_dit_workspace_bytes(const MmplDit* h, int n_frames) { return carve_fwd(h, n_frames, nullptr).bytes; }
+size_t mmpl_dit_context_workspace_bytes(const MmplDit* h) {
+  return 2 * (((size_t)h->cfg.text_len * h->cfg.dim * 2 + 255) & ~(size_t)255);
+}
+
+int mmpl_dit_precompute_context(MmplDit* h, const void* context, void* cross_k, void* cross_v, void* workspace,
+                                size_t workspace_bytes, mmpl_stream_t stream) {
+  if (!h || h->w.empty()) return fail("mmpl_dit_precompute_context", "weights not bound");
+  if (workspace_bytes < mmpl_dit_context_workspace_bytes(h)) return fail("mmpl_dit_precompute_context", "workspace too small");
+  const MmplDitConfig& c = h->cfg;
+  hipStream_t s = (hipStream_t)stream;
+  Carver k(workspace);
+  bf16_t* t0 = k.take((size_t)c.text_len * c.dim);
+  bf16_t* ctx = k.take((size_t)c.text_len * c.dim);
+  const int T = c.text_len, d = c.dim;
+  TRY(gemm((const bf16_t*)context, c.text_dim, h->G(G_TXT0_W), c.text_dim, h->G(G_TXT0_B), t0, d, T, d, c.text_dim,
+           EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 1, s));
+  TRY(gemm(t0, d, h->G(G_TXT2_W), d, h->G(G_TXT2_B), ctx, d, T, d, d, EPI_BIAS, nullptr, 0, nullptr, 0, 1, s));
+  for (int l = 0; l < c.num_layers; ++l) {
+    bf16_t* kl = (bf16_t*)cross_k + (size_t)l * T * d;
+    bf16_t* vl = (bf16_t*)cross_v + (size_t)l * T * d;
+    TRY(gemm(ctx, d, h->Lw(l, L_CK_W), d, h->Lw(l, L_CK_B), kl, d, T, d, d, EPI_BIAS, nullptr, 0, nullptr, 0, 1, s));
+    HIP_TRY(mmpl_launch_rmsnorm(kl, d, h->Lw(l, L_CNK), T, d, c.eps, s), "rmsnorm(ctx k)");
+    TRY(gemm(ctx, d, h->Lw(l, L_CV_W), d, h->Lw(l, L_CV_B), vl, d, T, d, d, EPI_BIAS, nullptr, 0, nullptr, 0, 1, s));
+  }
+  return 0;
+}
+
+int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, const int* frame_ids,
+                     const int* write_slots, const int* visible_slots, int n_visible, void* k_cache, void* v_cache,
+                     int n_slots, const void* cross_k, const void* cross_v, void* out, void* workspace,
+                     size_t workspace_bytes, mmpl_stream_t stream) {
+  if (!h || h->w.empty()) return fail("mmpl_dit_forward", "weights not bound");
+  const MmplDitConfig& c = h->cfg;
+  if (nF < 1 || nF > c.max_frames) return fail("mmpl_dit_forward", "n_frames out of range");
+  int n_write = 0;
+  for (int i = 0; i < nF; ++i) {
+    if (write_slots[i] >= n_slots) return fail("mmpl_dit_forward", "write slot out of range");
+    if (write_slots[i] >= 0) ++n_write;
+  }
+  if (n_write != 0 && n_write != nF) return fail("mmpl_dit_forward", "write_slots must be all >= 0 or all -1");
+  const bool persist = n_write == nF;
+  const int n_pages = n_visible + (persist ? 0 : nF);
+  if (n_pages < 1 || n_pages > MMPL_MAX_PAGES) return fail("mmpl_dit_forward", "too many / no visible KV pages");
+  for (int i = 0; i < n_visible; ++i)
+    if (visible_slots[i] < 0 || visible_slots[i] >= n_slots) return fail("mmpl_dit_forward", "visible slot out of range");
+  FwdWs w = carve_fwd(h, nF, workspace);
+  if (workspace_bytes < w.bytes) return fail("mmpl_dit_forward", "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int S = h->S, d = c.dim, f = c.ffn_dim, Lq = nF * S, H = c.num_heads, T = c.text_len;
+
+  // ---- embeddings (causal_fps_model.py:757-776)
+  HIP_TRY(mmpl_launch_patchify((const bf16_t*)x_in, w.patch, nF, c.in_dim, c.lat_h, c.lat_w, s), "patchify");
+  TRY(gemm(w.patch, 64, h->G(G_PE_W), 64, h->G(G_PE_B), w.x, d, Lq, d, 64, EPI_BIAS, nullptr, 0, nullptr, 0, 1, s));
+  HIP_TRY(mmpl_launch_sinusoid(t_dev, w.sinu, nF, c.freq_dim, s), "sinusoid");
+  TRY(gemm(w.sinu, c.freq_dim, h->G(G_TE0_W), c.freq_dim, h->G(G_TE0_B), w.t1, d, nF, d, c.freq_dim, EPI_BIAS_SILU, nullptr,
+           0, nullptr, 0, 1, s));
+  TRY(gemm(w.t1, d, h->G(G_TE2_W), d, h->G(G_TE2_B), w.e, d, nF, d, d, EPI_BIAS, nullptr, 0, nullptr, 0, 1, s));
+  HIP_TRY(mmpl_launch_silu(w.e, w.se, (size_t)nF * d, s), "silu");
+  TRY(gemm(w.se, d, h->G(G_TP_W), d, h->G(G_TP_B), w.e0, 6 * d, nF, 6 * d, d, EPI_BIAS, nullptr, 0, nullptr, 0, 1, s));
+  // e = bf16(modulation + e0) for every layer and for the head (causal_fps_model.py:338, 393)
+  HIP_TRY(mmpl_launch_modulation(h->G(G_BLOCK_MOD), (size_t)6 * d, w.e0, 6 * d, 0, w.emod, c.num_layers, nF, 6, d, s), "modulation");
+  HIP_TRY(mmpl_launch_modulation(h->G(G_HEAD_MOD), 0, w.e, d, 1, w.emod_head, 1, nF, 2, d, s), "head modulation");
+
+  const float scale = 1.0f / sqrtf(128.0f);
+  const size_t layer_stride = (size_t)n_slots * S * d;
+  for (int l = 0; l < c.num_layers; ++l) {
+    const bf16_t* em = w.emod + (size_t)l * nF * 6 * d;  // [nF][6][d]
+    bf16_t* kc = (bf16_t*)k_cache + (size_t)l * layer_stride;
+    bf16_t* vc = (bf16_t*)v_cache + (size_t)l * layer_stride;
+    // -- self attention (causal_fps_model.py:342-348)
+    {
+      LnArgs a{w.x, d, w.xn, d, Lq, d, c.eps, em + 1 * d, em + 0 * d, 6 * d, S, nullptr, nullptr};
+      HIP_TRY(mmpl_launch_layernorm(a, s), "norm1");
+    }
+    TRY(gemm(w.xn, d, h->Lw(l, L_QKV_W), d, h->Lw(l, L_QKV_B), w.big, 3 * d, Lq, 3 * d, d, EPI_BIAS, nullptr, 0, nullptr, 0, 1, s));
+    {
+      QkNormArgs a = {};
+      a.q = w.big; a.ldq = 3 * d; a.k = w.big + d; a.ldk = 3 * d; a.v = w.big + 2 * d; a.ldv = 3 * d;
+      a.wq = h->Lw(l, L_NQ); a.wk = h->Lw(l, L_NK); a.rows = Lq; a.d = d; a.eps = c.eps; a.rope = 1;
+      a.cos_tab = h->cos_tab; a.sin_tab = h->sin_tab; a.rows_per_frame = S; a.grid_w = h->gw;
+      for (int i = 0; i < nF; ++i) {
+        a.frame_ids[i] = frame_ids[i];
+        a.k_dst[i] = persist ? kc + (size_t)write_slots[i] * S * d : w.ksc + (size_t)i * S * d;
+        a.v_dst[i] = persist ? vc + (size_t)write_slots[i] * S * d : w.vsc + (size_t)i * S * d;
+      }
+      HIP_TRY(mmpl_launch_qknorm(a, s), "qk norm + rope + kv write");
+    }
+    {
+      AttnArgs a = {};
+      a.q = w.big; a.ldq = 3 * d; a.o = w.attn; a.ldo = d; a.ldk = d; a.ldv = d; a.page_rows = S; a.Lq = Lq; a.H = H; a.scale = scale;
+      int np = 0;
+      for (int i = 0; i < n_visible; ++i, ++np) {
+        a.k_pages[np] = kc + (size_t)visible_slots[i] * S * d;
+        a.v_pages[np] = vc + (size_t)visible_slots[i] * S * d;
+      }
+      if (!persist)
+        for (int i = 0; i < nF; ++i, ++np) {
+          a.k_pages[np] = w.ksc + (size_t)i * S * d;
+          a.v_pages[np] = w.vsc + (size_t)i * S * d;
+        }
+      a.n_pages = np;
+      HIP_TRY(mmpl_launch_attention(a, s), "self attention");
+    }
+    TRY(gemm(w.attn, d, h->Lw(l, L_O_W), d, h->Lw(l, L_O_B), w.x, d, Lq, d, d, EPI_GATE_RES, w.x, d, em + 2 * d, 6 * d, S, s));
+    // -- cross attention (causal_fps_model.py:352-353, model.py:161-194)
+    {
+      LnArgs a{w.x, d, w.xn, d, Lq, d, c.eps, nullptr, nullptr, 0, S, h->Lw(l, L_N3_W), h->Lw(l, L_N3_B)};
+      HIP_TRY(mmpl_launch_layernorm(a, s), "norm3");
+    }
+    TRY(gemm(w.xn, d, h->Lw(l, L_CQ_W), d, h->Lw(l, L_CQ_B), w.big, d, Lq, d, d, EPI_BIAS, nullptr, 0, nullptr, 0, 1, s));
+    HIP_TRY(mmpl_launch_rmsnorm(w.big, d, h->Lw(l, L_CNQ), Lq, d, c.eps, s), "cross q norm");
+    {
+      AttnArgs a = {};
+      a.q = w.big; a.ldq = d; a.o = w.attn; a.ldo = d; a.ldk = d; a.ldv = d; a.page_rows = T; a.Lq = Lq; a.H = H; a.scale = scale;
+      a.n_pages = 1;
+      a.k_pages[0] = (const bf16_t*)cross_k + (size_t)l * T * d;
+      a.v_pages[0] = (const bf16_t*)cross_v + (size_t)l * T * d;
+      HIP_TRY(mmpl_launch_attention(a, s), "cross attention");
+    }
+    TRY(gemm(w.attn, d, h->Lw(l, L_CO_W), d, h->Lw(l, L_CO_B), w.x, d, Lq, d, d, EPI_RES, w.x, d, nullptr, 0, 1, s));
+    // -- FFN (causal_fps_model.py:354-360)
+    {
+      LnArgs a{w.x, d, w.xn, d, Lq, d, c.eps, em + 4 * d, em + 3 * d, 6 * d, S, nullptr, nullptr};
+      HIP_TRY(mmpl_launch_layernorm(a, s), "norm2");
+    }
+    TRY(gemm(w.xn, d, h->Lw(l, L_F0_W), d, h->Lw(l, L_F0_B), w.big, f, Lq, f, d, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 1, s));
+    TRY(gemm(w.big, f, h->Lw(l, L_F2_W), f, h->Lw(l, L_F2_B), w.x, d, Lq, d, f, EPI_GATE_RES, w.x, d, em + 5 * d, 6 * d, S, s));
+  }
+  // ---- head + unpatchify (causal_fps_model.py:384-395, 1007-1030)
+  {
+    LnArgs a{w.x, d, w.xn, d, Lq, d, c.eps, w.emod_head + d, w.emod_head, 2 * d, S, nullptr, nullptr};
+    HIP_TRY(mmpl_launch_layernorm(a, s), "head norm");
+  }
+  TRY(gemm(w.xn, d, h->G(G_HEAD_W), d, h->G(G_HEAD_B), w.yh, 64, Lq, 64, d, EPI_BIAS, nullptr, 0, nullptr, 0, 1, s));
+  HIP_TRY(mmpl_launch_unpatchify(w.yh, 64, (bf16_t*)out, nF, c.out_dim, c.lat_h, c.lat_w, s), "unpatchify");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ single kernels
+int mmpl_attn_fwd(const void* q, int ldq, void* o, int ldo, const void* const* k_pages, const void* const* v_pages,
+                  int ldk, int ldv, int n_pages, int page_rows, int Lq, int num_heads, float softmax_scale,
+                  mmpl_stream_t stream) {
+  if (n_pages < 1 || n_pages > MMPL_MAX_PAGES) return fail("mmpl_attn_fwd", "n_pages out of range");
+  AttnArgs a = {};
+  a.q = (const bf16_t*)q; a.ldq = ldq; a.o = (bf16_t*)o; a.ldo = ldo; a.ldk = ldk; a.ldv = ldv; a.n_pages = n_pages;
+  a.page_rows = page_rows; a.Lq = Lq; a.H = num_heads; a.scale = softmax_scale;
+  for (int i = 0; i < n_pages; ++i) { a.k_pages[i] = (const bf16_t*)k_pages[i]; a.v_pages[i] = (const bf16_t*)v_pages[i]; }
+  HIP_TRY(mmpl_launch_attention(a, (hipStream_t)stream), "mmpl_attn_fwd");
+  return 0;
+}
+
+int mmpl_gemm(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N, int K,
+              int epi, const void* res, int ldres, const void* gate, int gate_frame_stride, int rows_per_frame,
+              mmpl_stream_t stream) {
+  if ((epi == EPI_GATE_RES && (!res || !gate)) || (epi == EPI_RES && !res)) return fail("mmpl_gemm", "missing epilogue operand");
+  return gemm((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (bf16_t*)C, ldc, M, N, K, epi,
+              (const bf16_t*)res, ldres, (const bf16_t*)gate, gate_frame_stride, rows_per_frame, (hipStream_t)stream);
+}
+
+int mmpl_layernorm(const void* x, int ldx, void* y, int ldy, int rows, int d, float eps, const void* scale,
+                   const void* shift, int mod_frame_stride, int rows_per_frame, const void* w, const void* b,
+                   mmpl_stream_t stream) {
+  if (!w && (!scale || !shift)) return fail("mmpl_layernorm", "need (scale, shift) or (w, b)");
+  LnArgs a{(const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, d, eps, (const bf16_t*)scale, (const bf16_t*)shift, mod_frame_stride,
+           rows_per_frame > 0 ? rows_per_frame : 1, (const bf16_t*)w, (const bf16_t*)b};
+  HIP_TRY(mmpl_launch_layernorm(a, (hipStream_t)stream), "mmpl_layernorm");
+  return 0;
+}
+
+int mmpl_qknorm_rope(MmplDit* h, void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* wq,
+                     const void* wk, int n_frames, const int* frame_ids, void* const* k_dst, void* const* v_dst,
+                     mmpl_stream_t stream) {
+  if (!h) return fail("mmpl_qknorm_rope", "null handle");
+  if (n_frames < 1 || n_frames > 8) return fail("mmpl_qknorm_rope", "n_frames out of range");
+  QkNormArgs a = {};
+  a.q = (bf16_t*)q; a.ldq = ldq; a.k = (const bf16_t*)k; a.ldk = ldk; a.v = (const bf16_t*)v; a.ldv = ldv;
+  a.wq = (const bf16_t*)wq; a.wk = (const bf16_t*)wk; a.rows = n_frames * h->S; a.d = h->cfg.dim; a.eps = h->cfg.eps; a.rope = 1;
+  a.cos_tab = h->cos_tab; a.sin_tab = h->sin_tab; a.rows_per_frame = h->S; a.grid_w = h->gw;
+  for (int i = 0; i < n_frames; ++i) { a.frame_ids[i] = frame_ids[i]; a.k_dst[i] = (bf16_t*)k_dst[i]; a.v_dst[i] = (bf16_t*)v_dst[i]; }
+  HIP_TRY(mmpl_launch_qknorm(a, (hipStream_t)stream), "mmpl_qknorm_rope");
+  return 0;
+}
+
+int mmpl_cfg_unipc_step(const void* flow_cond, const void* flow_uncond, void* x, void* m0, void* m1, void* last_sample,
+                        size_t n, const MmplUniPCStep* st, mmpl_stream_t stream) {
+  if (!st) return fail("mmpl_cfg_unipc_step", "null step");
+  UniPCArgs a = {};
+  a.flow_c = (const bf16_t*)flow_cond; a.flow_u = (const bf16_t*)flow_uncond; a.guidance = st->guidance; a.x = (bf16_t*)x;
+  a.m0 = (bf16_t*)m0; a.m1 = (bf16_t*)m1; a.last_sample = (bf16_t*)last_sample; a.n = n; a.sigma_cur = st->sigma_cur;
+  a.use_corrector = st->use_corrector; a.corr_order = st->corr_order; a.c_c1 = st->c_c1; a.c_c2 = st->c_c2; a.c_c3 = st->c_c3;
+  a.c_inv_rk = st->c_inv_rk; a.c_rho0 = st->c_rho0; a.c_rho_last = st->c_rho_last; a.pred_order = st->pred_order;
+  a.p_c1 = st->p_c1; a.p_c2 = st->p_c2; a.p_c3 = st->p_c3; a.p_inv_rk = st->p_inv_rk;
+  HIP_TRY(mmpl_launch_unipc(a, (hipStream_t)stream), "mmpl_cfg_unipc_step");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,311 @@
+// HBM-bound kernels of the Wan DiT forward: LayerNorm+modulate, full-dim QK RMSNorm + 3-axis RoPE + KV page
+// write, patchify / unpatchify, timestep sinusoid, modulation prep, CFG + UniPC step.
+// All of them move 16 B per lane, one wave per token row, fp32 statistics, and round to bf16 exactly where
+// the reference's bf16 module boundaries round (DESIGN.md "numerics").
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+MMPL_DEV void unpack8(const uint4& u, float (&f)[8]) {
+  f[0] = bf2f(u.x & 0xffff); f[1] = bf2f(u.x >> 16); f[2] = bf2f(u.y & 0xffff); f[3] = bf2f(u.y >> 16);
+  f[4] = bf2f(u.z & 0xffff); f[5] = bf2f(u.z >> 16); f[6] = bf2f(u.w & 0xffff); f[7] = bf2f(u.w >> 16);
+}
+MMPL_DEV uint4 pack8(const float (&f)[8]) {
+  uint4 u;
+  u.x = pack2bf(f[0], f[1]); u.y = pack2bf(f[2], f[3]); u.z = pack2bf(f[4], f[5]); u.w = pack2bf(f[6], f[7]);
+  return u;
+}
+
+// ------------------------------------------------------------------ LayerNorm (+ modulation | affine)
+// one wave per row; the row lives in registers (NIT chunks of 8 per lane) -> exact two-pass mean / variance.
+template <int NIT>
+__global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const int lane = threadIdx.x & 63;
+  const int nchunk = a.d >> 3;
+  const bf16_t* xp = a.x + (size_t)row * a.ldx;
+  float v[NIT][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int ch = lane + 64 * it;
+    if (ch < nchunk) {
+      const uint4 u = *reinterpret_cast<const uint4*>(xp + ch * 8);
+      unpack8(u, v[it]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += v[it][j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[it][j] = 0.f;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)a.d;
+  float sq = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int ch = lane + 64 * it;
+    if (ch < nchunk) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float dlt = v[it][j] - mean; sq += dlt * dlt; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)a.d + a.eps);
+  bf16_t* yp = a.y + (size_t)row * a.ldy;
+  const int frame = a.w ? 0 : row / a.rows_per_frame;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int ch = lane + 64 * it;
+    if (ch >= nchunk) continue;
+    float o[8];
+    if (a.w) {
+      float w[8], b[8];
+      unpack8(*reinterpret_cast<const uint4*>(a.w + ch * 8), w);
+      unpack8(*reinterpret_cast<const uint4*>(a.b + ch * 8), b);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (v[it][j] - mean) * rstd * w[j] + b[j];
+    } else {
+      float sc[8], sh[8];
+      unpack8(*reinterpret_cast<const uint4*>(a.scale + (size_t)frame * a.mod_frame_stride + ch * 8), sc);
+      unpack8(*reinterpret_cast<const uint4*>(a.shift + (size_t)frame * a.mod_frame_stride + ch * 8), sh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float n = rbf((v[it][j] - mean) * rstd);   // norm output is a bf16 tensor
+        const float s1 = rbf(1.0f + sc[j]);              // (1 + e) is a bf16 tensor
+        o[j] = rbf(n * s1) + sh[j];                      // product rounds, sum rounds at pack
+      }
+    }
+    *reinterpret_cast<uint4*>(yp + ch * 8) = pack8(o);
+  }
+}
+
+// ------------------------------------------------------------------ QK RMSNorm (+RoPE, +KV page write)
+// one wave per token row.  Each lane's 16-B chunks sit at the same position inside a head for every
+// iteration (64*8 elements = 4 heads per sweep), so its 4 rotary pairs' cos/sin are loaded once per row.
+template <int NIT>
+__global__ __launch_bounds__(256) void qknorm_kernel(QkNormArgs a) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const int lane = threadIdx.x & 63;
+  const int nchunk = a.d >> 3;
+  const int lf = a.rope ? row / a.rows_per_frame : 0;             // local frame
+  const int tok = a.rope ? row - lf * a.rows_per_frame : row;     // token inside the frame
+  float cs[4], sn[4];
+  if (a.rope) {
+    const int gy = tok / a.grid_w, gx = tok - gy * a.grid_w, ft = a.frame_ids[lf];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p = 4 * (lane & 15) + j;                          // rotary pair index inside the head, 0..63
+      const int pos = p < 22 ? ft : (p < 43 ? gy : gx);           // split (22, 21, 21): causal_fps_model.py:31
+      cs[j] = a.cos_tab[pos * 64 + p];
+      sn[j] = a.sin_tab[pos * 64 + p];
+    }
+  }
+  const int n_mat = a.k ? 2 : 1;
+  for (int which = 0; which < n_mat; ++which) {
+    const bf16_t* src = which == 0 ? a.q + (size_t)row * a.ldq : a.k + (size_t)row * a.ldk;
+    const bf16_t* gain = which == 0 ? a.wq : a.wk;
+    float v[NIT][8];
+    float sq = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int ch = lane + 64 * it;
+      if (ch < nchunk) {
+        unpack8(*reinterpret_cast<const uint4*>(src + ch * 8), v[it]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sq += v[it][j] * v[it][j];
+      }
+    }
+    const float rr = rsqrtf(wave_sum(sq) / (float)a.d + a.eps);
+    bf16_t* dst = which == 0 ? a.q + (size_t)row * a.ldq
+                             : (a.k_dst[lf] + (size_t)tok * a.d);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int ch = lane + 64 * it;
+      if (ch >= nchunk) continue;
+      float w[8], o[8];
+      unpack8(*reinterpret_cast<const uint4*>(gain + ch * 8), w);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = rbf(rbf(v[it][j] * rr) * w[j]);   // norm.type_as(x) * weight
+      if (a.rope) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float re = o[2 * j], im = o[2 * j + 1];
+          o[2 * j] = re * cs[j] - im * sn[j];
+          o[2 * j + 1] = re * sn[j] + im * cs[j];
+        }
+      }
+      *reinterpret_cast<uint4*>(dst + ch * 8) = pack8(o);
+    }
+  }
+  if (a.v) {  // V is copied unchanged into its page
+    const bf16_t* src = a.v + (size_t)row * a.ldv;
+    bf16_t* dst = a.v_dst[lf] + (size_t)tok * a.d;
+    for (int ch = lane; ch < nchunk; ch += 64)
+      *reinterpret_cast<uint4*>(dst + ch * 8) = *reinterpret_cast<const uint4*>(src + ch * 8);
+  }
+}
+
+// ------------------------------------------------------------------ small kernels
+__global__ void modulation_kernel(const bf16_t* mod, size_t mod_layer_stride, const bf16_t* e, int e_frame_stride, int bcast,
+                                  bf16_t* emod, int n_layers, int n_frames, int nmod, int d) {
+  const size_t per_frame = (size_t)nmod * d;
+  const size_t total = (size_t)n_layers * n_frames * per_frame;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t within = i % per_frame;
+    const size_t lf = i / per_frame;
+    const int f = (int)(lf % n_frames), l = (int)(lf / n_frames);
+    const size_t ei = (size_t)f * e_frame_stride + (bcast ? within % d : within);
+    emod[i] = f2bf(bf2f(mod[(size_t)l * mod_layer_stride + within]) + bf2f(e[ei]));
+  }
+}
+
+__global__ void patchify_kernel(const bf16_t* x, bf16_t* a, int F, int C, int h, int w) {
+  const int gh = h >> 1, gw = w >> 1;
+  const size_t total = (size_t)F * gh * gw * C * 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % (C * 4));
+    const size_t tokg = i / (C * 4);
+    const int c = col >> 2, ph = (col >> 1) & 1, pw = col & 1;
+    const int gx = (int)(tokg % gw), gy = (int)((tokg / gw) % gh), f = (int)(tokg / ((size_t)gw * gh));
+    a[i] = x[(((size_t)f * C + c) * h + (2 * gy + ph)) * w + 2 * gx + pw];
+  }
+}
+
+__global__ void unpatchify_kernel(const bf16_t* y, int ldy, bf16_t* out, int F, int C, int h, int w) {
+  const int gh = h >> 1, gw = w >> 1;
+  const size_t total = (size_t)F * C * h * w;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % w), yy = (int)((i / w) % h), c = (int)((i / ((size_t)w * h)) % C),
+              f = (int)(i / ((size_t)w * h * C));
+    const size_t tok = ((size_t)f * gh + (yy >> 1)) * gw + (xx >> 1);
+    out[i] = y[tok * ldy + ((yy & 1) * 2 + (xx & 1)) * C + c];       // 'fhwpqrc->cfphqwr'
+  }
+}
+
+__global__ void sinusoid_kernel(const float* t, bf16_t* out, int F, int freq_dim) {
+  const int half = freq_dim >> 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F * half) return;
+  const int f = i / half, k = i - f * half;
+  const double ang = (double)t[f] * pow(10000.0, -(double)k / (double)half);   // model.py:19-24 (float64)
+  out[(size_t)f * freq_dim + k] = f2bf((float)cos(ang));
+  out[(size_t)f * freq_dim + half + k] = f2bf((float)sin(ang));
+}
+
+__global__ void silu_kernel(const bf16_t* x, bf16_t* y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    y[i] = f2bf(silu(bf2f(x[i])));
+}
+
+// ------------------------------------------------------------------ CFG + FlowUniPC (order <= 2, bh2, predict_x0)
+// Every tensor op of fm_solvers_unipc.py:315-331 / 486-626 / 350-484 on a bf16 tensor rounds to bf16; this kernel
+// performs the same chain per element with the same rounding points.  Scalars come from the host scheduler.
+__global__ void unipc_kernel(UniPCArgs a) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
+    float flow = bf2f(a.flow_c[i]);
+    if (a.flow_u) {
+      const float fu = bf2f(a.flow_u[i]);
+      flow = rbf(fu + rbf(a.guidance * rbf(flow - fu)));            // casual_fps_inference.py:366-367
+    }
+    float x = bf2f(a.x[i]);
+    const float m_conv = rbf(x - rbf(a.sigma_cur * flow));           // convert_model_output
+    float m0 = bf2f(a.m0[i]), m1 = bf2f(a.m1[i]);
+    if (a.use_corrector) {
+      const float ls = bf2f(a.last_sample[i]);
+      const float xt_ = rbf(rbf(a.c_c1 * ls) - rbf(a.c_c2 * m0));
+      const float d1t = rbf(m_conv - m0);
+      float acc = rbf(a.c_rho_last * d1t);
+      if (a.corr_order == 2) {
+        const float d1 = rbf(rbf(m1 - m0) * a.c_inv_rk);
+        acc = rbf(rbf(a.c_rho0 * d1) + acc);
+      }
+      x = rbf(xt_ - rbf(a.c_c3 * acc));
+    }
+    m1 = m0;
+    m0 = m_conv;
+    a.m1[i] = f2bf(m1);
+    a.m0[i] = f2bf(m0);
+    a.last_sample[i] = f2bf(x);
+    float xt = rbf(rbf(a.p_c1 * x) - rbf(a.p_c2 * m0));
+    if (a.pred_order == 2) {
+      const float d1 = rbf(rbf(m1 - m0) * a.p_inv_rk);
+      xt = rbf(xt - rbf(a.p_c3 * rbf(0.5f * d1)));
+    }
+    a.x[i] = f2bf(xt);
+  }
+}
+
+inline int grid_for(size_t n, int block = 256) {
+  size_t g = (n + block - 1) / block;
+  return (int)(g > 2048 * 4 ? 2048 * 4 : (g == 0 ? 1 : g));
+}
+
+}  // namespace
+
+#define DISPATCH_NIT(NITV, KERNEL, ARGS, ROWS, STREAM)                                                     \
+  switch (NITV) {                                                                                          \
+    case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(((ROWS) + 3) / 4), dim3(256), 0, STREAM, ARGS); break;      \
+    case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(((ROWS) + 3) / 4), dim3(256), 0, STREAM, ARGS); break;      \
+    case 3: hipLaunchKernelGGL(KERNEL<3>, dim3(((ROWS) + 3) / 4), dim3(256), 0, STREAM, ARGS); break;      \
+    case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(((ROWS) + 3) / 4), dim3(256), 0, STREAM, ARGS); break;      \
+    case 5: case 6: hipLaunchKernelGGL(KERNEL<6>, dim3(((ROWS) + 3) / 4), dim3(256), 0, STREAM, ARGS); break; \
+    case 7: case 8: hipLaunchKernelGGL(KERNEL<8>, dim3(((ROWS) + 3) / 4), dim3(256), 0, STREAM, ARGS); break; \
+    case 9: case 10: hipLaunchKernelGGL(KERNEL<10>, dim3(((ROWS) + 3) / 4), dim3(256), 0, STREAM, ARGS); break; \
+    default: return hipErrorInvalidValue;                                                                  \
+  }
+
+hipError_t mmpl_launch_layernorm(const LnArgs& a, hipStream_t s) {
+  if (a.rows <= 0) return hipSuccess;
+  if (a.d % 8 || a.d > 5120 || a.ldx % 8 || a.ldy % 8) return hipErrorInvalidValue;
+  const int nit = (a.d / 8 + 63) / 64;
+  DISPATCH_NIT(nit, layernorm_kernel, a, a.rows, s);
+  return hipGetLastError();
+}
+
+hipError_t mmpl_launch_qknorm(const QkNormArgs& a, hipStream_t s) {
+  if (a.rows <= 0) return hipSuccess;
+  if (a.d % 128 || a.d > 5120 || a.ldq % 8 || a.ldk % 8 || a.ldv % 8) return hipErrorInvalidValue;
+  const int nit = (a.d / 8 + 63) / 64;
+  DISPATCH_NIT(nit, qknorm_kernel, a, a.rows, s);
+  return hipGetLastError();
+}
+
+hipError_t mmpl_launch_rmsnorm(bf16_t* x, int ldx, const bf16_t* w, int rows, int d, float eps, hipStream_t s) {
+  QkNormArgs a = {};
+  a.q = x; a.ldq = ldx; a.wq = w; a.rows = rows; a.d = d; a.eps = eps; a.rope = 0; a.rows_per_frame = rows > 0 ? rows : 1;
+  a.grid_w = 1;
+  return mmpl_launch_qknorm(a, s);
+}
+
+hipError_t mmpl_launch_modulation(const bf16_t* mod, size_t mod_layer_stride, const bf16_t* e, int e_frame_stride, int bcast,
+                                  bf16_t* emod, int n_layers, int n_frames, int nmod, int d, hipStream_t s) {
+  const size_t n = (size_t)n_layers * n_frames * nmod * d;
+  hipLaunchKernelGGL(modulation_kernel, dim3(grid_for(n)), dim3(256), 0, s, mod, mod_layer_stride, e, e_frame_stride, bcast, emod,
+                     n_layers, n_frames, nmod, d);
+  return hipGetLastError();
+}
+hipError_t mmpl_launch_patchify(const bf16_t* x, bf16_t* a, int F, int C, int h, int w, hipStream_t s) {
+  const size_t n = (size_t)F * C * h * w;
+  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, a, F, C, h, w);
+  return hipGetLastError();
+}
+hipError_t mmpl_launch_unpatchify(const bf16_t* y, int ldy, bf16_t* out, int F, int C, int h, int w, hipStream_t s) {
+  const size_t n = (size_t)F * C * h * w;
+  hipLaunchKernelGGL(unpatchify_kernel, dim3(grid_for(n)), dim3(256), 0, s, y, ldy, out, F, C, h, w);
+  return hipGetLastError();
+}
+hipError_t mmpl_launch_sinusoid(const float* t, bf16_t* out, int F, int freq_dim, hipStream_t s) {
+  const int n = F * (freq_dim / 2);
+  hipLaunchKernelGGL(sinusoid_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t, out, F, freq_dim);
+  return hipGetLastError();
+}
+hipError_t mmpl_launch_silu(const bf16_t* x, bf16_t* y, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(silu_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, n);
+  return hipGetLastError();
+}
+hipError_t mmpl_launch_unipc(const UniPCArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(unipc_kernel, dim3(grid_for(a.n)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}

@@ -1,0 +1,91 @@
+// Internal launcher interface between the C-ABI layer (api.hip) and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "common.h"
+
+// ---------------------------------------------------------------- GEMM (gemm.hip)
+enum GemmEpi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_SILU = 2, EPI_GATE_RES = 3, EPI_RES = 4 };
+struct GemmArgs {
+  const bf16_t* A; int lda;      // [M, K]
+  const bf16_t* W; int ldw;      // [N, K]  (nn.Linear weight)
+  const bf16_t* bias;            // [N] or null
+  bf16_t* C; int ldc;            // [M, N]
+  int M, N, K;
+  int epi;
+  const bf16_t* res; int ldres;  // residual x for EPI_GATE_RES / EPI_RES (may alias C)
+  const bf16_t* gate;            // per-frame gate vectors: gate[frame * gate_frame_stride + n]
+  int gate_frame_stride;
+  int rows_per_frame;
+};
+hipError_t mmpl_launch_gemm(const GemmArgs& g, hipStream_t s);
+
+// ---------------------------------------------------------------- attention (attention.hip)
+constexpr int MMPL_MAX_PAGES = 24;
+struct AttnArgs {
+  const bf16_t* q; int ldq;       // row r, head h at q + r*ldq + h*128
+  bf16_t* o; int ldo;
+  const bf16_t* k_pages[MMPL_MAX_PAGES];   // page p: row j, head h at k_pages[p] + j*ldk + h*128
+  const bf16_t* v_pages[MMPL_MAX_PAGES];
+  int ldk, ldv;
+  int n_pages, page_rows;
+  int Lq, H;
+  float scale;                     // softmax scale (1/sqrt(128))
+};
+hipError_t mmpl_launch_attention(const AttnArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- norms / rope / elementwise (elementwise.hip)
+// LayerNorm (eps, fp32 stats) fused with per-frame modulation  y = bf16(bf16(LN(x)) * bf16(1+scale)) + shift
+// or with an affine (w, b).  mod pointers index [frame * mod_frame_stride + col].
+struct LnArgs {
+  const bf16_t* x; int ldx;
+  bf16_t* y; int ldy;
+  int rows, d;
+  float eps;
+  const bf16_t* scale; const bf16_t* shift; int mod_frame_stride; int rows_per_frame;  // modulation form
+  const bf16_t* w; const bf16_t* b;                                                    // affine form (if w != null)
+};
+hipError_t mmpl_launch_layernorm(const LnArgs& a, hipStream_t s);
+
+// Full-dim RMSNorm (+ optional 3-axis RoPE, + optional K/V page write) on the fused qkv projection.
+struct QkNormArgs {
+  bf16_t* q; int ldq;                 // in/out (in place)
+  const bf16_t* k; int ldk;           // in (null: q only)
+  const bf16_t* v; int ldv;           // in
+  const bf16_t* wq; const bf16_t* wk; // RMSNorm gains [d]
+  int rows, d;
+  float eps;
+  int rope;                           // 0: no rope (cross-attn q / context k)
+  const float* cos_tab; const float* sin_tab;  // [1024][64] fp32
+  int frame_ids[8];                   // temporal rope position per local frame
+  bf16_t* k_dst[8]; bf16_t* v_dst[8]; // per local frame destination page base (row stride = d); k_out for no-page mode
+  int rows_per_frame, grid_w;
+};
+hipError_t mmpl_launch_qknorm(const QkNormArgs& a, hipStream_t s);
+
+// rmsnorm of a plain [rows, d] matrix in place (context K)
+hipError_t mmpl_launch_rmsnorm(bf16_t* x, int ldx, const bf16_t* w, int rows, int d, float eps, hipStream_t s);
+
+// emod[l][f][k][:] = bf16(mod[l*mod_layer_stride + k*d + :] + e[f*e_frame_stride + (bcast ? : : k*d + :)])   (k < nmod)
+hipError_t mmpl_launch_modulation(const bf16_t* mod, size_t mod_layer_stride, const bf16_t* e, int e_frame_stride, int bcast,
+                                  bf16_t* emod, int n_layers, int n_frames, int nmod, int d, hipStream_t s);
+// patchify: x[F, C=16, h, w] -> A[F*gh*gw, 64]  (col = c*4 + ph*2 + pw)
+hipError_t mmpl_launch_patchify(const bf16_t* x, bf16_t* a, int F, int C, int h, int w, hipStream_t s);
+// unpatchify: y[F*gh*gw, 4*C] (col = (ph*2+pw)*C + c) -> out[F, C, h, w]
+hipError_t mmpl_launch_unpatchify(const bf16_t* y, int ldy, bf16_t* out, int F, int C, int h, int w, hipStream_t s);
+// sinusoidal timestep embedding (fp64 math): t[F] fp32 -> out[F, freq_dim] bf16 ([cos | sin])
+hipError_t mmpl_launch_sinusoid(const float* t, bf16_t* out, int F, int freq_dim, hipStream_t s);
+hipError_t mmpl_launch_silu(const bf16_t* x, bf16_t* y, size_t n, hipStream_t s);
+
+// CFG combine + one FlowUniPC step (elementwise.hip); scalars computed on the host exactly as the reference does
+struct UniPCArgs {
+  const bf16_t* flow_c; const bf16_t* flow_u;   // flow_u == null: flow_c is already the combined flow
+  float guidance;
+  bf16_t* x;          // sample in / next sample out
+  bf16_t* m0; bf16_t* m1; bf16_t* last_sample;   // solver state (updated in place)
+  size_t n;
+  float sigma_cur;
+  int use_corrector, corr_order; float c_c1, c_c2, c_c3, c_inv_rk, c_rho0, c_rho_last;
+  int pred_order; float p_c1, p_c2, p_c3, p_inv_rk;
+};
+hipError_t mmpl_launch_unipc(const UniPCArgs& a, hipStream_t s);

@@ -1,0 +1,135 @@
+"""Host-side handle of the HIP Wan DiT forward (libmmpl_hip.so: mmpl_dit_*).
+
+Mirrors what ``CausalFPSWanModel`` (MMPL_t2v/wan/modules/causal_fps_model.py:398-530, 708-837) offers the
+wrapper: construct from the model dims, ``load_state_dict`` with the reference's keys, run one inference
+forward against a per-layer KV cache.  PyTorch only owns the device memory here; all compute is in the library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+_GLOBAL_KEYS = ["patch_embedding.weight", "patch_embedding.bias", "text_embedding.0.weight", "text_embedding.0.bias",
+                "text_embedding.2.weight", "text_embedding.2.bias", "time_embedding.0.weight", "time_embedding.0.bias",
+                "time_embedding.2.weight", "time_embedding.2.bias", "time_projection.1.weight", "time_projection.1.bias",
+                "head.modulation", "head.head.weight", "head.head.bias"]
+
+
+class DitEngine:
+    def __init__(self, cfg: dict, lat_h: int, lat_w: int, device="cuda:0", max_frames: int = 7):
+        self.cfg = dict(cfg)
+        self.device = torch.device(device)
+        self.lat_h, self.lat_w = lat_h, lat_w
+        self.S = (lat_h // 2) * (lat_w // 2)
+        self.dim, self.L = cfg["dim"], cfg["num_layers"]
+        self.text_len = cfg.get("text_len", 512)
+        self.text_dim = cfg.get("text_dim", 4096)
+        self.max_frames = max_frames
+        lib = _lib.load()
+        self._lib = lib
+        c = _lib.MmplDitConfig(dim=cfg["dim"], ffn_dim=cfg["ffn_dim"], num_heads=cfg["num_heads"],
+                               num_layers=cfg["num_layers"], text_dim=self.text_dim, freq_dim=cfg.get("freq_dim", 256),
+                               in_dim=16, out_dim=16, text_len=self.text_len, eps=cfg.get("eps", 1e-6), lat_h=lat_h,
+                               lat_w=lat_w, max_frames=max_frames)
+        self._c = c
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.mmpl_dit_create(C.byref(c), C.byref(h)), "mmpl_dit_create")
+        self._h = h
+        self._weights: List[torch.Tensor] = []
+        self._ws: Dict[int, torch.Tensor] = {}
+        self._ctx_ws: Optional[torch.Tensor] = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.mmpl_dit_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = "") -> None:
+        """sd uses the reference's CausalFPSWanModel keys (optionally prefixed, e.g. 'model.' in MMPL .pt files,
+        Wan_fps_inference_1gpu.py:66-68).  q/k/v are packed into one [3*dim, dim] operand."""
+        dev, bf = self.device, torch.bfloat16
+
+        def g(k):
+            return sd[prefix + k].to(device=dev, dtype=bf).contiguous()
+
+        w: List[torch.Tensor] = []
+        for k in _GLOBAL_KEYS:
+            t = g(k)
+            if k == "patch_embedding.weight":
+                t = t.reshape(t.shape[0], -1).contiguous()
+            w.append(t)
+        w.append(torch.stack([g(f"blocks.{i}.modulation").reshape(6, self.dim) for i in range(self.L)]).contiguous())
+        for i in range(self.L):
+            p = f"blocks.{i}."
+            w.append(torch.cat([g(p + "self_attn.q.weight"), g(p + "self_attn.k.weight"), g(p + "self_attn.v.weight")]).contiguous())
+            w.append(torch.cat([g(p + "self_attn.q.bias"), g(p + "self_attn.k.bias"), g(p + "self_attn.v.bias")]).contiguous())
+            for k in ("self_attn.norm_q.weight", "self_attn.norm_k.weight", "self_attn.o.weight", "self_attn.o.bias",
+                      "norm3.weight", "norm3.bias", "cross_attn.q.weight", "cross_attn.q.bias", "cross_attn.norm_q.weight",
+                      "cross_attn.k.weight", "cross_attn.k.bias", "cross_attn.norm_k.weight", "cross_attn.v.weight",
+                      "cross_attn.v.bias", "cross_attn.o.weight", "cross_attn.o.bias", "ffn.0.weight", "ffn.0.bias",
+                      "ffn.2.weight", "ffn.2.bias"):
+                w.append(g(p + k))
+        n = self._lib.mmpl_dit_num_weights(C.byref(self._c))
+        assert len(w) == n, (len(w), n)
+        arr = (C.c_void_p * n)(*[t.data_ptr() for t in w])
+        _lib.check(self._lib.mmpl_dit_bind_weights(self._h, arr, n), "mmpl_dit_bind_weights")
+        self._weights = w      # keep alive: the library borrows the pointers
+
+    # ------------------------------------------------------------------ caches
+    def new_kv_cache(self, n_slots: int = 15) -> Tuple[torch.Tensor, torch.Tensor]:
+        """[num_layers, n_slots*S, dim] K and V; layer l is the reference's kv_cache[l]['k'] viewed [1, n_slots*S, H, 128]
+        (casual_fps_inference.py:453-480)."""
+        shape = (self.L, n_slots * self.S, self.dim)
+        return (torch.zeros(shape, dtype=torch.bfloat16, device=self.device),
+                torch.zeros(shape, dtype=torch.bfloat16, device=self.device))
+
+    def precompute_context(self, context: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """context: [L<=text_len, text_dim] -> per-layer cross-attention (K, V) [num_layers, text_len, dim]."""
+        ctx = torch.zeros(self.text_len, self.text_dim, dtype=torch.bfloat16, device=self.device)
+        ctx[:context.shape[0]] = context.to(device=self.device, dtype=torch.bfloat16)
+        ck = torch.empty(self.L, self.text_len, self.dim, dtype=torch.bfloat16, device=self.device)
+        cv = torch.empty_like(ck)
+        if self._ctx_ws is None:
+            self._ctx_ws = torch.empty(self._lib.mmpl_dit_context_workspace_bytes(self._h), dtype=torch.uint8, device=self.device)
+        _lib.check(self._lib.mmpl_dit_precompute_context(self._h, _lib.ptr(ctx), _lib.ptr(ck), _lib.ptr(cv), _lib.ptr(self._ctx_ws),
+                                                         self._ctx_ws.numel(), _lib.stream_ptr()), "precompute_context")
+        return ck, cv
+
+    def workspace(self, n_frames: int) -> torch.Tensor:
+        if n_frames not in self._ws:
+            nbytes = self._lib.mmpl_dit_workspace_bytes(self._h, n_frames)
+            # one buffer sized for the largest stage serves all stages
+            big = max(self._ws.values(), key=lambda t: t.numel(), default=None)
+            if big is not None and big.numel() >= nbytes:
+                self._ws[n_frames] = big
+            else:
+                self._ws[n_frames] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws[n_frames]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor, t: torch.Tensor, frame_ids: Sequence[int], write_slots: Sequence[int],
+                visible_slots: Sequence[int], k_cache: torch.Tensor, v_cache: torch.Tensor, cross_k: torch.Tensor,
+                cross_v: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x: [nF, 16, lat_h, lat_w] bf16; t: [nF] float32 (device).  Returns flow prediction, same shape as x."""
+        nF = x.shape[0]
+        assert x.is_contiguous() and x.dtype == torch.bfloat16 and x.shape[1:] == (16, self.lat_h, self.lat_w)
+        assert t.dtype == torch.float32 and t.numel() == nF and t.is_cuda
+        if out is None:
+            out = torch.empty_like(x)
+        ws = self.workspace(nF)
+        n_slots = k_cache.shape[1] // self.S
+        ia = lambda v: (C.c_int * len(v))(*[int(i) for i in v])
+        _lib.check(self._lib.mmpl_dit_forward(
+            self._h, _lib.ptr(x), _lib.ptr(t), nF, ia(frame_ids), ia(write_slots), ia(visible_slots), len(visible_slots),
+            _lib.ptr(k_cache), _lib.ptr(v_cache), n_slots, _lib.ptr(cross_k), _lib.ptr(cross_v), _lib.ptr(out), _lib.ptr(ws),
+            ws.numel(), _lib.stream_ptr()), "mmpl_dit_forward")
+        return out

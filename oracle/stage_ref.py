@@ -72,7 +72,8 @@ class VisIndex:
 def run_chunk(p: Dict[str, torch.Tensor], cfg: W.DitCfg, noise: torch.Tensor, ctx_cond: torch.Tensor,
               ctx_uncond: torch.Tensor, renoise: Optional[Dict[int, torch.Tensor]] = None,
               initial_latent: Optional[torch.Tensor] = None, mode: str = "t2v", guidance: float = 5.0,
-              steps: int = 50, shift: float = 5.0, attn_fn=W.sdpa, trace: Optional[list] = None):
+              steps: int = 50, shift: float = 5.0, attn_fn=W.sdpa, trace: Optional[list] = None,
+              gpu_scalar_semantics: bool = False):
     """noise: [1, 21, 16, h, w]; renoise: {frame: [1,16,h,w]} replacements for frames 4,9,13,18 (t2v only);
     initial_latent: [1, 2, 16, h, w] or None.  Returns (output latents [1,21,16,h,w], hand-off tensor)."""
     clean = T2V_CLEAN_STEPS if mode == "t2v" else I2V_CLEAN_STEPS
@@ -118,12 +119,12 @@ def run_chunk(p: Dict[str, torch.Tensor], cfg: W.DitCfg, noise: torch.Tensor, ct
                 latents[:, 0:1] = renoise[frames[0]].unsqueeze(1)              # add_noise(t>=1000) == fresh noise
                 latents[:, -1:] = renoise[frames[-1]].unsqueeze(1)
             (vis[0].hide(), vis[1].hide()) if si == 2 else (vis[0].show(), vis[1].show())
-        sched = FlowUniPCRef(1000, 2, 1.0)
+        sched = FlowUniPCRef(1000, 2, 1.0, gpu_scalar_semantics)
         sched.set_timesteps(steps, shift=shift)
         for t in sched.timesteps:
             fc = fwd(0, latents, t.item(), frames)
             fu = fwd(1, latents, t.item(), frames)
-            flow = fu + guidance * (fc - fu)                                      # :366-367
+            flow = fu + guidance * (fc - fu)                                      # :366-367 (python float: fp32 on CPU and GPU)
             latents = sched.step(flow, latents)
             if trace is not None:
                 trace.append((si, int(t), flow.clone(), latents.clone()))
