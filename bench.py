@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Headline benchmark: chunk-AR denoising throughput of Wan2.1-T2V-14B at 720p latent shapes on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One *step* = one denoise step of the reference's hot loop (MMPL_t2v/pipeline/casual_fps_inference.py:338-374):
+cond DiT forward + uncond DiT forward (separate KV caches) + CFG combine + UniPC update, all HIP.  Steps rotate
+through the four T2V stage shapes s0..s3 (2/7/6/6 query frames attending 2/9/13/21 frames), so K steps (K % 4 == 0)
+sample every stage equally.  A first chunk is 4 stages x (50 denoise steps + 1 cache-refresh pair) = 204
+step-equivalents (408 forwards), hence
+
+    latent-frames/s = 21 / (204 * mean step time)          (whole-job: summed over ranks, each rank = one chunk)
+
+Inputs (weights, KV caches, context, latents) are synthetic and resident in HBM before the timed region.
+Extra JSON objects: `roofline` for the dominant kernel (self-attention; MFMA bound) from hipEvent pairs recorded
+around every launch inside the timed region, `cpu_baseline` = the oracle (a CPU port) timed on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+KIND_NAMES = ["gemm", "attn_self", "attn_cross", "layernorm", "qknorm_rope", "elementwise", "cfg_unipc", "vae"]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--model", default="14B", choices=["14B", "1.3B", "small", "tiny"])
+    ap.add_argument("--res", default="720p", choices=["480p", "720p", "tiny"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="disable the per-kernel hipEvent pairs")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, lat_h, lat_w, chunk_flops):
+    """Oracle (CPU port of the reference path) on a bounded sample: ONE transformer block of the benchmarked model
+    at the s0 stage shape (2 query frames attending 2 frames), all host threads.  Reported in the metric's unit by
+    scaling with algorithmic FLOPs (a chunk is ~481 PFLOP at 14B/720p -- hours on a CPU)."""
+    from mmpl_amd.synthetic import dit_state_dict
+    from oracle import wan_dit_ref as W
+    one = dict(cfg, num_layers=1)
+    ocfg = W.DitCfg(**one)
+    sd = dit_state_dict(one, seed=0)
+    gh, gw = lat_h // 2, lat_w // 2
+    S, nF = gh * gw, 2
+    x = torch.randn(1, nF * S, ocfg.dim).to(torch.bfloat16)
+    e0 = (torch.randn(1, nF, 6, ocfg.dim) * 0.1).to(torch.bfloat16)
+    ctx = torch.randn(1, 512, ocfg.dim).to(torch.bfloat16)
+    kv = W.new_kv_cache(ocfg, 2, S)[0]
+    ck, cv = W.cross_kv(sd, ocfg, 0, ctx)
+    freqs = W.rope_table(128)
+    t0 = time.time()
+    with torch.no_grad():
+        W.block_forward(sd, ocfg, 0, x, e0, kv, ck, cv, [0, 1], [0, 1], [0, 1], S, gh, gw, freqs)
+    dt = time.time() - t0
+    Lq = nF * S
+    flops = 2.0 * Lq * (6.0 * ocfg.dim ** 2 + 2.0 * ocfg.dim * ocfg.ffn_dim) + 4.0 * Lq * Lq * ocfg.dim + 4.0 * Lq * 512 * ocfg.dim
+    rate = flops / dt
+    return {"value": 21.0 / (chunk_flops / rate), "unit": "latent-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle block_forward, 1 of {cfg['num_layers']} blocks, stage s0 (Lq=Lkv={Lq}), {dt:.1f} s, "
+                      f"{rate / 1e12:.3f} TFLOP/s; extrapolated by algorithmic FLOPs to one 408-forward chunk"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    assert args.steps % 4 == 0 and args.steps > 0, "--steps must be a positive multiple of 4 (one per T2V stage shape)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    from mmpl_amd import _lib
+    from mmpl_amd.dit import DitEngine
+    from mmpl_amd.geometry import RESOLUTIONS
+    from mmpl_amd.scheduler import FlowUniPCMultistepScheduler
+    from mmpl_amd.stage_plan import N_SLOTS, T2V_STAGE_SHAPES, StagePlan, dit_forward_flops, slot_of
+    from mmpl_amd.synthetic import WAN_CONFIGS, dit_state_dict
+
+    lib = _lib.load()
+    cfg = WAN_CONFIGS[args.model]
+    lat_h, lat_w = (16, 24) if args.res == "tiny" else RESOLUTIONS[args.res]
+    eng = DitEngine(cfg, lat_h, lat_w, dev)
+    eng.load_state_dict(dit_state_dict(cfg, seed=1234, device=dev))
+    S = eng.S
+    plan = StagePlan("t2v")
+
+    # two KV caches (cond / uncond) filled with unit-variance data so softmax sees realistic score spreads
+    caches = []
+    for i in range(2):
+        kc, vc = eng.new_kv_cache(N_SLOTS)
+        kc.normal_()
+        vc.normal_()
+        ctx = torch.randn(512, cfg["text_dim"], device=dev).to(torch.bfloat16)
+        ctx[64:] = 0
+        ck, cv = eng.precompute_context(ctx)
+        caches.append((kc, vc, ck, cv))
+    # per-stage state: latents, visible slots, scheduler
+    vis_frames = [[0, 1], [0, 1, 2, 3, 10, 11, 12, 19, 20], list(range(13)), list(range(13)) + [19, 20]]
+    stage_state = []
+    for si, frames in enumerate(plan.stages):
+        lat = torch.randn(len(frames), 16, lat_h, lat_w, device=dev).to(torch.bfloat16)
+        sched = FlowUniPCMultistepScheduler(1000, 2, 1.0)
+        sched.set_timesteps(50, shift=5.0)
+        vis = [slot_of(f) for f in vis_frames[si]]
+        stage_state.append(dict(frames=frames, lat=lat, sched=sched, vis=vis, ws=plan.write_slots(frames),
+                                fc=torch.empty_like(lat), fu=torch.empty_like(lat),
+                                t=torch.empty(len(frames), dtype=torch.float32, device=dev)))
+    handoff_send = torch.zeros(8, 16, lat_h, lat_w, device=dev, dtype=torch.bfloat16)
+    handoff_recv = torch.zeros_like(handoff_send)
+    side = torch.cuda.Stream(device=dev)
+
+    def one_step(i):
+        st = stage_state[i % 4]
+        sched = st["sched"]
+        if sched.step_index >= 50:
+            sched.set_timesteps(50, shift=5.0)
+        st["t"].fill_(float(sched.timesteps[sched.step_index]))
+        for which, out in ((0, st["fc"]), (1, st["fu"])):
+            kc, vc, ck, cv = caches[which]
+            eng.forward(st["lat"], st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out)
+        sched.step_cfg(st["fc"], st["fu"], 5.0, st["lat"])
+        if dist is not None and i % 4 == 1:
+            # chunk hand-off of the anchor stage (casual_fps_inference.py:380-383 -> RCCL p2p on a side stream,
+            # overlapped with the next stage's compute): rank r -> r+1
+            handoff_send[0].copy_(st["lat"][0])
+            handoff_send[1:].copy_(st["lat"])
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                ops = []
+                if rank + 1 < world:
+                    ops.append(dist.P2POp(dist.isend, handoff_send, rank + 1))
+                if rank > 0:
+                    ops.append(dist.P2POp(dist.irecv, handoff_recv, rank - 1))
+                if ops:
+                    for w in dist.batch_isend_irecv(ops):
+                        w.wait()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    barrier()
+    if not args.no_profile:
+        lib.mmpl_profile_enable(1)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(i)
+    torch.cuda.current_stream().wait_stream(side)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = None
+    if not args.no_profile:
+        n = len(KIND_NAMES)
+        ms, fl, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_longlong * n)()
+        lib.mmpl_profile_read(n, ms, fl, cnt)
+        lib.mmpl_profile_enable(0)
+        prof = {KIND_NAMES[k]: dict(ms=ms[k], flops=fl[k], launches=int(cnt[k])) for k in range(n) if cnt[k]}
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        chunk_s = 204.0 * elapsed / args.steps
+        value = world * 21.0 / chunk_s
+        stage_flops = [dit_forward_flops(cfg, S, q, kv) for q, kv in T2V_STAGE_SHAPES]
+        chunk_flops = 102.0 * sum(stage_flops)
+        step_flops = 2.0 * sum(stage_flops) / 4.0                       # mean over the rotation, 2 forwards per step
+        achieved_pf = step_flops / (elapsed / args.steps) / 1e15
+        res = {
+            "metric": "video_latent_frames_per_sec", "value": value, "unit": "latent-frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Wan2.1-T2V-{args.model} {args.res} chunk-AR denoise step (cond+uncond DiT forward, CFG, UniPC), "
+                                   f"rotating T2V stages s0..s3; one 21-latent-frame chunk per GPU = 204 step-equivalents",
+                       "frame_seqlen": S, "latent_hw": [lat_h, lat_w], "sampling_steps": 50, "guidance_scale": 5.0,
+                       "parallelism": f"chunk-per-rank x{world}" + (" + RCCL p2p anchor hand-off r->r+1" if world > 1 else "")},
+            "sec_per_denoise_step": elapsed / args.steps,
+            "sec_per_chunk_extrapolated": chunk_s,
+            "achieved_pflops_per_gpu": achieved_pf,
+            "mfma_frac_whole_step": achieved_pf * 1e3 / MFMA_PEAK_TFLOPS,
+        }
+        if prof and "attn_self" in prof:
+            a = prof["attn_self"]
+            ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
+            res["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel (self-attention over the KV-slot page table)",
+                               "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+                               "traffic": None, "avg_launch_ms": a["ms"] / a["launches"], "launches": a["launches"],
+                               "algorithmic_flops_per_launch": a["flops"] / a["launches"]}
+            tot = sum(v["ms"] for v in prof.values())
+            res["kernel_time_share"] = {k: round(v["ms"] / tot, 4) for k, v in prof.items()}
+            if "gemm" in prof:
+                g = prof["gemm"]
+                res["gemm_tflops"] = g["flops"] / (g["ms"] * 1e-3) / 1e12
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                res["cpu_baseline"] = cpu_baseline(cfg, lat_h, lat_w, chunk_flops)
+            except Exception as e:  # the baseline is a reported extra; never lose the GPU measurement over it
+                res["cpu_baseline"] = {"value": None, "unit": "latent-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                                       "sample": f"failed: {e!r}"}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -97,6 +97,12 @@ typedef struct MmplUniPCStep {
 int mmpl_cfg_unipc_step(const void* flow_cond, const void* flow_uncond, void* x, void* m0, void* m1, void* last_sample,
                         size_t n, const MmplUniPCStep* s, mmpl_stream_t stream);
 
+/* Optional per-kernel-class hipEvent timing (bench.py's live roofline numbers; off by default, not thread-safe).
+ * kinds: 0 gemm, 1 self-attention, 2 cross-attention, 3 layernorm, 4 qk-norm/rope/kv-write, 5 elementwise, 6 cfg+unipc,
+ * 7 vae.  mmpl_profile_read synchronises the device, sums the event pairs recorded since enable/last read. */
+int mmpl_profile_enable(int on);
+int mmpl_profile_read(int n_kinds, double* ms, double* flops, long long* launches);
+
 const char* mmpl_last_error(void);
 const char* mmpl_version(void);
 

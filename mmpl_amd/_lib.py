@@ -12,8 +12,7 @@ SYMBOLS = [
     "mmpl_dit_num_weights", "mmpl_dit_weight_name", "mmpl_dit_create", "mmpl_dit_destroy", "mmpl_dit_bind_weights",
     "mmpl_dit_workspace_bytes", "mmpl_dit_context_workspace_bytes", "mmpl_dit_precompute_context", "mmpl_dit_forward",
     "mmpl_attn_fwd", "mmpl_gemm", "mmpl_layernorm", "mmpl_qknorm_rope", "mmpl_cfg_unipc_step",
-    "mmpl_vae_create", "mmpl_vae_destroy", "mmpl_vae_bind_weights", "mmpl_vae_workspace_bytes", "mmpl_vae_decode",
-    "mmpl_vae_encode", "mmpl_last_error", "mmpl_version",
+    "mmpl_profile_enable", "mmpl_profile_read", "mmpl_last_error", "mmpl_version",
 ]
 
 
@@ -65,6 +64,8 @@ def load() -> C.CDLL:
     lib.mmpl_layernorm.argtypes = [vp, ci, vp, ci, ci, ci, cf, vp, vp, ci, ci, vp, vp, vp]
     lib.mmpl_qknorm_rope.argtypes = [vp, vp, ci, vp, ci, vp, ci, vp, vp, ci, C.POINTER(ci), C.POINTER(vp), C.POINTER(vp), vp]
     lib.mmpl_cfg_unipc_step.argtypes = [vp, vp, vp, vp, vp, vp, sz, C.POINTER(MmplUniPCStep), vp]
+    lib.mmpl_profile_enable.argtypes = [ci]
+    lib.mmpl_profile_read.argtypes = [ci, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     if hasattr(lib, "mmpl_vae_create"):
         _bind_vae(lib)
     _lib = lib

@@ -22,6 +22,42 @@ static int fail(const char* where, const char* what) {
     if (e__ != hipSuccess) return fail(where, hipGetErrorString(e__)); \
   } while (0)
 
+// ---- optional per-kernel-class timing (bench / profiling only; not thread-safe, off by default)
+enum { K_GEMM, K_ATTN_SELF, K_ATTN_CROSS, K_LAYERNORM, K_QKNORM, K_ELEMENTWISE, K_UNIPC, K_VAE, K_NKINDS };
+namespace {
+struct Prof {
+  bool on = false;
+  std::vector<hipEvent_t> ev;
+  std::vector<int> kind;
+  std::vector<double> flops;
+  size_t used = 0;  // pairs
+} g_prof;
+struct ProfScope {
+  hipStream_t s;
+  bool active;
+  ProfScope(int kind, double flops, hipStream_t st) : s(st), active(g_prof.on) {
+    if (!active) return;
+    if (g_prof.ev.size() < 2 * (g_prof.used + 1)) {
+      hipEvent_t a, b;
+      hipEventCreate(&a);
+      hipEventCreate(&b);
+      g_prof.ev.push_back(a);
+      g_prof.ev.push_back(b);
+      g_prof.kind.push_back(0);
+      g_prof.flops.push_back(0);
+    }
+    g_prof.kind[g_prof.used] = kind;
+    g_prof.flops[g_prof.used] = flops;
+    hipEventRecord(g_prof.ev[2 * g_prof.used], s);
+  }
+  ~ProfScope() {
+    if (!active) return;
+    hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
+    ++g_prof.used;
+  }
+};
+}  // namespace
+
 enum {  // global weight slots
   G_PE_W, G_PE_B, G_TXT0_W, G_TXT0_B, G_TXT2_W, G_TXT2_B, G_TE0_W, G_TE0_B, G_TE2_W, G_TE2_B, G_TP_W, G_TP_B,
   G_HEAD_MOD, G_HEAD_W, G_HEAD_B, G_BLOCK_MOD, NG
@@ -53,6 +89,25 @@ struct MmplDit {
 };
 
 extern "C" {
+
+int mmpl_profile_enable(int on) {
+  g_prof.on = on != 0;
+  g_prof.used = 0;
+  return 0;
+}
+int mmpl_profile_read(int n_kinds, double* ms, double* flops, long long* launches) {
+  if (n_kinds > K_NKINDS) n_kinds = K_NKINDS;
+  for (int i = 0; i < n_kinds; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; }
+  if (hipDeviceSynchronize() != hipSuccess) return fail("mmpl_profile_read", "sync failed");
+  for (size_t i = 0; i < g_prof.used; ++i) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) continue;
+    const int k = g_prof.kind[i];
+    if (k < n_kinds) { ms[k] += t; flops[k] += g_prof.flops[i]; launches[k] += 1; }
+  }
+  g_prof.used = 0;
+  return 0;
+}
 
 const char* mmpl_last_error(void) { return g_err.c_str(); }
 const char* mmpl_version(void) { return "mmpl_hip 0.1 (gfx950)"; }
@@ -163,6 +218,7 @@ FwdWs carve_fwd(const MmplDit* h, int nF, void* base) {
 int gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, bf16_t* C, int ldc, int M, int N, int K,
          int epi, const bf16_t* res, int ldres, const bf16_t* gate, int gfs, int rpf, hipStream_t s) {
   GemmArgs g{A, lda, W, ldw, bias, C, ldc, M, N, K, epi, res, ldres, gate, gfs, rpf > 0 ? rpf : 1};
+  ProfScope ps(K_GEMM, 2.0 * M * (double)N * K, s);
   hipError_t e = mmpl_launch_gemm(g, s);
   if (e != hipSuccess) return fail("gemm", hipGetErrorString(e));
   return 0;
@@ -245,6 +301,7 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
     // -- self attention (causal_fps_model.py:342-348)
     {
       LnArgs a{w.x, d, w.xn, d, Lq, d, c.eps, em + 1 * d, em + 0 * d, 6 * d, S, nullptr, nullptr};
+      ProfScope ps(K_LAYERNORM, 0, s);
       HIP_TRY(mmpl_launch_layernorm(a, s), "norm1");
     }
     TRY(gemm(w.xn, d, h->Lw(l, L_QKV_W), d, h->Lw(l, L_QKV_B), w.big, 3 * d, Lq, 3 * d, d, EPI_BIAS, nullptr, 0, nullptr, 0, 1, s));
@@ -258,6 +315,7 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
         a.k_dst[i] = persist ? kc + (size_t)write_slots[i] * S * d : w.ksc + (size_t)i * S * d;
         a.v_dst[i] = persist ? vc + (size_t)write_slots[i] * S * d : w.vsc + (size_t)i * S * d;
       }
+      ProfScope ps(K_QKNORM, 0, s);
       HIP_TRY(mmpl_launch_qknorm(a, s), "qk norm + rope + kv write");
     }
     {
@@ -274,28 +332,35 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
           a.v_pages[np] = w.vsc + (size_t)i * S * d;
         }
       a.n_pages = np;
+      ProfScope ps(K_ATTN_SELF, 4.0 * Lq * (double)np * S * d, s);
       HIP_TRY(mmpl_launch_attention(a, s), "self attention");
     }
     TRY(gemm(w.attn, d, h->Lw(l, L_O_W), d, h->Lw(l, L_O_B), w.x, d, Lq, d, d, EPI_GATE_RES, w.x, d, em + 2 * d, 6 * d, S, s));
     // -- cross attention (causal_fps_model.py:352-353, model.py:161-194)
     {
       LnArgs a{w.x, d, w.xn, d, Lq, d, c.eps, nullptr, nullptr, 0, S, h->Lw(l, L_N3_W), h->Lw(l, L_N3_B)};
+      ProfScope ps(K_LAYERNORM, 0, s);
       HIP_TRY(mmpl_launch_layernorm(a, s), "norm3");
     }
     TRY(gemm(w.xn, d, h->Lw(l, L_CQ_W), d, h->Lw(l, L_CQ_B), w.big, d, Lq, d, d, EPI_BIAS, nullptr, 0, nullptr, 0, 1, s));
-    HIP_TRY(mmpl_launch_rmsnorm(w.big, d, h->Lw(l, L_CNQ), Lq, d, c.eps, s), "cross q norm");
+    {
+      ProfScope ps(K_QKNORM, 0, s);
+      HIP_TRY(mmpl_launch_rmsnorm(w.big, d, h->Lw(l, L_CNQ), Lq, d, c.eps, s), "cross q norm");
+    }
     {
       AttnArgs a = {};
       a.q = w.big; a.ldq = d; a.o = w.attn; a.ldo = d; a.ldk = d; a.ldv = d; a.page_rows = T; a.Lq = Lq; a.H = H; a.scale = scale;
       a.n_pages = 1;
       a.k_pages[0] = (const bf16_t*)cross_k + (size_t)l * T * d;
       a.v_pages[0] = (const bf16_t*)cross_v + (size_t)l * T * d;
+      ProfScope ps(K_ATTN_CROSS, 4.0 * Lq * (double)T * d, s);
       HIP_TRY(mmpl_launch_attention(a, s), "cross attention");
     }
     TRY(gemm(w.attn, d, h->Lw(l, L_CO_W), d, h->Lw(l, L_CO_B), w.x, d, Lq, d, d, EPI_RES, w.x, d, nullptr, 0, 1, s));
     // -- FFN (causal_fps_model.py:354-360)
     {
       LnArgs a{w.x, d, w.xn, d, Lq, d, c.eps, em + 4 * d, em + 3 * d, 6 * d, S, nullptr, nullptr};
+      ProfScope ps(K_LAYERNORM, 0, s);
       HIP_TRY(mmpl_launch_layernorm(a, s), "norm2");
     }
     TRY(gemm(w.xn, d, h->Lw(l, L_F0_W), d, h->Lw(l, L_F0_B), w.big, f, Lq, f, d, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 1, s));
@@ -365,6 +430,7 @@ int mmpl_cfg_unipc_step(const void* flow_cond, const void* flow_uncond, void* x,
   a.use_corrector = st->use_corrector; a.corr_order = st->corr_order; a.c_c1 = st->c_c1; a.c_c2 = st->c_c2; a.c_c3 = st->c_c3;
   a.c_inv_rk = st->c_inv_rk; a.c_rho0 = st->c_rho0; a.c_rho_last = st->c_rho_last; a.pred_order = st->pred_order;
   a.p_c1 = st->p_c1; a.p_c2 = st->p_c2; a.p_c3 = st->p_c3; a.p_inv_rk = st->p_inv_rk;
+  ProfScope ps(K_UNIPC, 0, (hipStream_t)stream);
   HIP_TRY(mmpl_launch_unipc(a, (hipStream_t)stream), "mmpl_cfg_unipc_step");
   return 0;
 }

@@ -1,0 +1,181 @@
+"""``CausalFPSInferencePipeline`` -- drop-in for MMPL_t2v/pipeline/casual_fps_inference.py (and the I2V variant,
+MMPL_i2v/pipeline/casual_fps_inference.py) with the denoising hot loop on the HIP engines.
+
+Same constructor / ``inference()`` signature, attributes (``generator_cond``, ``vae``, ``text_encoder``,
+``independent_first_frame``, ``need_wait``, ``save``) and stage semantics.  What changed
+underneath, MI355X-first:
+  * one DiT forward = one C call (``mmpl_dit_forward``), K/V read in place through the slot table -- no gather copies,
+    no host syncs inside a forward;
+  * CFG + UniPC = one fused kernel per step (``mmpl_cfg_unipc_step``);
+  * nothing is shuffled to the CPU (T5 / VAE stay resident: 288 GB HBM);
+  * the literals 1560 / 40x128 / 40 blocks are derived from a ``Geometry`` and the model config;
+  * the hand-off is delivered to ``self.handoff_sink`` (default: ``torch.save(self.save)`` like the reference; the
+    multi-GPU runner installs an RCCL send, mmpl_amd/handoff.py).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional
+
+import torch
+
+from ..geometry import Geometry
+from ..scheduler import FlowUniPCMultistepScheduler
+from ..stage_plan import StagePlan
+from ..wan_wrapper import WanFPSWrapper, WanTextEncoder, WanVAEWrapper
+
+
+class CausalFPSInferencePipeline(torch.nn.Module):
+    def __init__(self, args, device, generator=None, text_encoder=None, vae=None, device_cond="cuda:0",
+                 device_uncond="cuda:0", save="latents_chunk1.pt", mode: str = "t2v", geometry: Optional[Geometry] = None):
+        super().__init__()
+        self.need_wait = False
+        self.save = save
+        self.device_cond = device_cond
+        self.device_uncond = device_uncond
+        self.mode = mode
+        self.plan = StagePlan(mode)
+        self.geometry = geometry or (generator.geometry if generator is not None else Geometry.named("480p"))
+
+        self.generator_cond = WanFPSWrapper(**getattr(args, "model_kwargs", {}), is_causal=True, geometry=self.geometry,
+                                            device=device_cond) if generator is None else generator
+        self.generator_cond.model.num_frame_per_block = 1
+        self.text_encoder = WanTextEncoder() if text_encoder is None else text_encoder
+        self.vae = WanVAEWrapper(geometry=self.geometry, device=device_cond) if vae is None else vae
+
+        self.num_train_timesteps = args.num_train_timestep
+        self.sampling_steps = getattr(args, "sampling_steps", 50)
+        self.sample_solver = "unipc"
+        self.shift = args.timestep_shift
+        self.num_transformer_blocks = self.generator_cond.engine.L
+        self.frame_seq_length = self.geometry.frame_seqlen
+
+        self.kv_cache_pos = None
+        self.kv_cache_neg = None
+        self.crossattn_cache_pos = None
+        self.crossattn_cache_neg = None
+        self.args = args
+        self.num_frame_per_block = 1
+        self.independent_first_frame = args.independent_first_frame
+        self.local_attn_size = -1
+        self.handoff_sink: Optional[Callable[[torch.Tensor], None]] = None
+
+        # ---- "add new noise on previous frames" schedule (casual_fps_inference.py:93-108); the randint keeps the
+        # reference's RNG consumption order; the resulting timestep is >= 1000, i.e. pure noise
+        self.ddpm_scheduler = self.generator_cond.get_scheduler()
+        self.image_or_video_shape = [1, 1, 16, self.geometry.lat_h, self.geometry.lat_w]
+        self.ddpm_index = torch.randint(980, self.num_train_timesteps, [1, 1], device=self.device_cond, dtype=torch.long)
+        self.ddmp_timestep = self.ddpm_scheduler.timesteps.to(self.ddpm_index.device)[self.ddpm_index] + 1000
+
+    def to(self, *args, **kwargs):
+        return self
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _forward(self, latents, cond, timestep, kv, cross, frames, out=None):
+        S = self.frame_seq_length
+        starts = [f * S for f in frames]
+        return self.generator_cond(noisy_image_or_video=latents, conditional_dict=cond, timestep=timestep, kv_cache=kv,
+                                   crossattn_cache=cross, current_start=starts, cache_start=starts, out=out)[0]
+
+    def _refresh(self, latents, cond, uncond, timestep, frames):
+        """rerun with timestep zero to update the KV cache with clean context (:385-403)."""
+        self._forward(latents, cond, timestep * 0, self.kv_cache_pos, self.crossattn_cache_pos, frames)
+        self._forward(latents, uncond, timestep * 0, self.kv_cache_neg, self.crossattn_cache_neg, frames)
+
+    def inference(self, noise: torch.Tensor, text_prompts: List[str], initial_latent: Optional[torch.Tensor] = None,
+                  return_latents: bool = False, start_frame_index: Optional[int] = 0, decode: bool = True):
+        """noise: [1, 21, 16, h, w]; initial_latent: [1, n, 16, h, w] (T2V chunks >= 2: n = 2; I2V: n = 1 image latent,
+        chunks >= 2: n = 2).  Returns video [1, T, 3, 8h, 8w] in [0, 1] (and the latents)."""
+        batch_size, num_frames, num_channels, height, width = noise.shape
+        assert batch_size == 1 and num_frames == self.geometry.frames_per_chunk
+        dev = noise.device
+        with torch.no_grad():
+            conditional_dict = self.text_encoder(text_prompts=text_prompts)
+            unconditional_dict = self.text_encoder(text_prompts=[self.args.negative_prompt] * len(text_prompts))
+
+            output = torch.zeros_like(noise)
+            if self.kv_cache_pos is None:
+                self.kv_cache_pos = self.generator_cond.new_kv_cache()
+                self.kv_cache_neg = self.generator_cond.new_kv_cache()
+                self.crossattn_cache_pos = self.generator_cond.new_crossattn_cache()
+                self.crossattn_cache_neg = self.generator_cond.new_crossattn_cache()
+            else:
+                for c in (self.crossattn_cache_pos, self.crossattn_cache_neg):
+                    for blk in c:
+                        blk["is_init"] = False
+                self.kv_cache_pos.reset()
+                self.kv_cache_neg.reset()
+
+            stages = self.plan.stages
+            S = self.frame_seq_length
+            first = 0
+            if initial_latent is not None:
+                n_init = initial_latent.shape[1]
+                if self.mode == "t2v":                                        # t2v :407-439
+                    groups = [(stages[0], initial_latent)]
+                    first = 1
+                else:                                                         # i2v :368-435
+                    groups = [(stages[j], initial_latent[:, j:j + 1]) for j in range(n_init)]
+                    first = n_init
+                for frames, lat in groups:
+                    lat = lat.to(device=dev, dtype=noise.dtype).contiguous()
+                    t0 = torch.zeros([1, len(frames)], device=dev, dtype=torch.float32)
+                    self._refresh(lat, conditional_dict, unconditional_dict, t0, frames)
+                    output[:, frames] = lat
+            elif self.mode == "i2v":
+                raise ValueError("I2V needs the VAE-encoded image as initial_latent")
+
+            for si in range(first, len(stages)):
+                frames = stages[si]
+                latents = noise[:, frames].contiguous()
+                if self.plan.renoised_frames(si):                             # :279-326
+                    src = (3, 10) if si == 2 else (12, 19)
+                    for pos, s in ((0, src[0]), (-1, src[1])):
+                        sl = slice(0, 1) if pos == 0 else slice(-1, None)
+                        latents[:, sl] = self.ddpm_scheduler.add_noise(
+                            output[:, s:s + 1].flatten(0, 1), torch.randn_like(latents[:, sl]).flatten(0, 1),
+                            self.ddmp_timestep.flatten(0, 1)).unflatten(0, (1, 1))
+                if self.plan.hides_anchors(si):
+                    for cache in (self.kv_cache_pos, self.kv_cache_neg):
+                        for v in (20 * S, 19 * S):
+                            if v in cache.vis:
+                                cache.vis.remove(v)
+                elif self.plan.shows_anchors(si):
+                    for cache in (self.kv_cache_pos, self.kv_cache_neg):
+                        for v in (20 * S, 19 * S):
+                            if v not in cache.vis:
+                                cache.vis.append(v)
+
+                sample_scheduler = self._initialize_sample_scheduler(noise)
+                flow_c = torch.empty_like(latents)
+                flow_u = torch.empty_like(latents)
+                timestep = torch.empty([1, len(frames)], device=dev, dtype=torch.float32)
+                for t in sample_scheduler.timesteps:
+                    timestep.fill_(float(t))
+                    self._forward(latents, conditional_dict, timestep, self.kv_cache_pos, self.crossattn_cache_pos, frames, flow_c)
+                    self._forward(latents, unconditional_dict, timestep, self.kv_cache_neg, self.crossattn_cache_neg, frames, flow_u)
+                    # flow = uncond + g (cond - uncond); latents = scheduler.step(flow)  -- one fused kernel (:366-374)
+                    sample_scheduler.step_cfg(flow_c, flow_u, self.args.guidance_scale, latents)
+
+                output[:, frames] = latents
+                if si == self.plan.handoff_stage:                             # t2v :380-383, i2v :340-343
+                    save_latents = (torch.cat([output[:, :1], latents], dim=1) if self.mode == "t2v"
+                                    else torch.cat([output[:, :1], output[:, -2:]], dim=1))
+                    if self.handoff_sink is not None:
+                        self.handoff_sink(save_latents)
+                    elif self.save:
+                        torch.save(save_latents, self.save)
+                self._refresh(latents, conditional_dict, unconditional_dict, timestep, frames)
+
+            video = None
+            if decode:
+                video = self.vae.decode_to_pixel(output)
+                video = (video * 0.5 + 0.5).clamp(0, 1)
+        if return_latents:
+            return video, output
+        return video
+
+    def _initialize_sample_scheduler(self, noise):
+        s = FlowUniPCMultistepScheduler(num_train_timesteps=self.num_train_timesteps, shift=1, use_dynamic_shifting=False)
+        s.set_timesteps(self.sampling_steps, device=noise.device, shift=self.shift)
+        self.timesteps = s.timesteps
+        return s

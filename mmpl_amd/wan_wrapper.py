@@ -1,0 +1,234 @@
+"""Model wrappers with the reference's names and call shapes (MMPL_t2v/utils/wan_wrapper.py), on the HIP engines.
+
+  * ``WanFPSWrapper``   (:317-515)  generator: forward(noisy, conditional_dict, timestep, kv_cache, crossattn_cache,
+                                    current_start, cache_start) -> (flow_pred, pred_x0)
+  * ``WanVAEWrapper``   (:54-113)   decode_to_pixel / encode_to_latent
+  * ``WanTextEncoder``  (:15-51)    seam only (umT5-xxl is outside this round's hot path)
+
+KV caches keep the reference's shape of a list of per-layer dicts (``k``, ``v``, ``attention_vis_index`` ...,
+pipeline/casual_fps_inference.py:453-501) so pipeline-style code runs unchanged, but the per-layer tensors are views
+into ONE allocation per cache that the HIP forward addresses through its slot table.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, List, Optional
+
+import torch
+
+from .dit import DitEngine
+from .geometry import Geometry
+from .scheduler import FlowMatchScheduler
+from .stage_plan import StagePlan, slot_of
+from .synthetic import WAN_CONFIGS
+
+local_wan_path = "../wan_models"
+
+
+class KVCache(list):
+    """list of per-layer dicts like the reference's kv_cache; `k_all` / `v_all`: [L, n_slots*S, dim]."""
+
+    def __init__(self, engine: DitEngine, n_slots: int = 15):
+        super().__init__()
+        self.engine = engine
+        self.k_all, self.v_all = engine.new_kv_cache(n_slots)
+        self.vis: List[int] = []          # token offsets, shared by every layer (the reference keeps L identical copies)
+        H = engine.cfg["num_heads"]
+        for l in range(engine.L):
+            self.append({"k": self.k_all[l].view(1, -1, H, 128), "v": self.v_all[l].view(1, -1, H, 128),
+                         "global_end_index": torch.tensor([0], dtype=torch.long),
+                         "local_end_index": torch.tensor([0], dtype=torch.long),
+                         "attention_vis_index": self.vis})
+
+    def reset(self):
+        self.vis.clear()
+
+
+class CrossAttnCache(list):
+    """list of per-layer dicts {"k","v","is_init"}; K/V for all layers are filled by one precompute call."""
+
+    def __init__(self, engine: DitEngine):
+        super().__init__()
+        self.engine = engine
+        self.k_all = torch.zeros(engine.L, engine.text_len, engine.dim, dtype=torch.bfloat16, device=engine.device)
+        self.v_all = torch.zeros_like(self.k_all)
+        H = engine.cfg["num_heads"]
+        for l in range(engine.L):
+            self.append({"k": self.k_all[l].view(1, -1, H, 128), "v": self.v_all[l].view(1, -1, H, 128), "is_init": False})
+
+    @property
+    def is_init(self) -> bool:
+        return all(b["is_init"] for b in self)
+
+    def fill(self, prompt_embeds: torch.Tensor):
+        ck, cv = self.engine.precompute_context(prompt_embeds)
+        self.k_all.copy_(ck)
+        self.v_all.copy_(cv)
+        for b in self:
+            b["is_init"] = True
+
+
+class _ModelHandle:
+    """What the pipeline touches on `generator.model` (num_frame_per_block, parameters())."""
+
+    def __init__(self, engine: DitEngine):
+        self.engine = engine
+        self.num_frame_per_block = 1
+
+    def parameters(self):
+        return iter(self.engine._weights)
+
+
+class WanFPSWrapper(torch.nn.Module):
+    def __init__(self, model_name="Wan2.1-T2V-14B", timestep_shift=8.0, is_causal=False, local_attn_size=-1, sink_size=0,
+                 *, model_config: Optional[dict] = None, geometry: Optional[Geometry] = None, device="cuda:0"):
+        super().__init__()
+        assert is_causal, "only the causal FPS generator is on the hot path"
+        self.geometry = geometry or Geometry.named("480p")
+        cfg = model_config
+        wdir = f"{local_wan_path}/{model_name}/"
+        if cfg is None and os.path.exists(os.path.join(wdir, "config.json")):
+            with open(os.path.join(wdir, "config.json")) as f:
+                j = json.load(f)
+            cfg = dict(dim=j["dim"], ffn_dim=j["ffn_dim"], num_heads=j["num_heads"], num_layers=j["num_layers"],
+                       text_dim=j.get("text_dim", 4096), freq_dim=j.get("freq_dim", 256))
+        if cfg is None:
+            key = "14B" if "14B" in model_name else "1.3B"
+            cfg = WAN_CONFIGS[key]
+        self.engine = DitEngine(cfg, self.geometry.lat_h, self.geometry.lat_w, device)
+        self.model = _ModelHandle(self.engine)
+        self._maybe_load_pretrained(wdir)
+        self.uniform_timestep = not is_causal
+        self.scheduler = FlowMatchScheduler(shift=timestep_shift, sigma_min=0.0, extra_one_step=True)
+        self.scheduler.set_timesteps(1000, training=True)
+        self.seq_len = self.geometry.frame_seqlen * self.geometry.frames_per_chunk
+
+    def _maybe_load_pretrained(self, wdir: str):
+        """diffusers-style dir: config.json + diffusion_pytorch_model*.safetensors."""
+        if not os.path.isdir(wdir):
+            return
+        files = sorted(f for f in os.listdir(wdir) if f.startswith("diffusion_pytorch_model") and f.endswith(".safetensors"))
+        if not files:
+            return
+        from safetensors.torch import load_file
+        sd: Dict[str, torch.Tensor] = {}
+        for f in files:
+            sd.update(load_file(os.path.join(wdir, f)))
+        self.engine.load_state_dict(sd)
+
+    # nn.Module-compatible entry points the entry scripts use
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """MMPL .pt checkpoints hold {'generator': {'model.<key>': tensor}} (Wan_fps_inference_1gpu.py:66-68)."""
+        prefix = "model." if any(k.startswith("model.") for k in state_dict) else ""
+        self.engine.load_state_dict(state_dict, prefix=prefix)
+        return torch.nn.modules.module._IncompatibleKeys([], [])
+
+    def to(self, *args, **kwargs):
+        return self                       # weights already live on the GPU in bf16
+
+    def get_scheduler(self):
+        return self.scheduler
+
+    def new_kv_cache(self, n_slots: int = 15) -> KVCache:
+        return KVCache(self.engine, n_slots)
+
+    def new_crossattn_cache(self) -> CrossAttnCache:
+        return CrossAttnCache(self.engine)
+
+    def forward(self, noisy_image_or_video: torch.Tensor, conditional_dict: dict, timestep: torch.Tensor,
+                kv_cache: Optional[KVCache] = None, crossattn_cache: Optional[CrossAttnCache] = None,
+                current_start=None, classify_mode=False, concat_time_embeddings=False, clean_x=None, aug_t=None,
+                cache_start=None, out: Optional[torch.Tensor] = None, return_x0: bool = False):
+        assert kv_cache is not None and crossattn_cache is not None, "the FPS path always runs with caches"
+        assert noisy_image_or_video.shape[0] == 1, "batch size 1 (as every reference entry point)"
+        S = self.engine.S
+        if not crossattn_cache.is_init:                                   # model.py:175-180
+            pe = conditional_dict["prompt_embeds"]
+            crossattn_cache.fill(pe[0] if pe.dim() == 3 else pe)
+        starts = [int(s) for s in current_start]
+        frames = [s // S for s in starts]
+        vis = kv_cache.vis
+        if 15 * S not in starts:                                          # causal_fps_model.py:209,219 / 255
+            for s in starts:
+                if s not in vis:
+                    vis.append(s)
+        x = noisy_image_or_video[0]
+        if x.dtype != torch.bfloat16 or not x.is_contiguous():
+            x = x.to(torch.bfloat16).contiguous()
+        t = timestep.reshape(-1).to(device=x.device, dtype=torch.float32)
+        y = self.engine.forward(x, t, frames, StagePlan.write_slots(frames), [slot_of(o // S) for o in vis],
+                                kv_cache.k_all, kv_cache.v_all, crossattn_cache.k_all, crossattn_cache.v_all,
+                                out=None if out is None else out[0])
+        flow_pred = y.unsqueeze(0)
+        pred_x0 = None
+        if return_x0:                                                     # wan_wrapper.py:373-397 (unused by the pipeline)
+            sig = self.scheduler.sigmas.double().to(x.device)
+            ts = self.scheduler.timesteps.double().to(x.device)
+            tid = torch.argmin((ts.unsqueeze(0) - t.double().unsqueeze(1)).abs(), dim=1)
+            pred_x0 = (x.double() - sig[tid].reshape(-1, 1, 1, 1) * y.double()).to(y.dtype).unsqueeze(0)
+        return flow_pred, pred_x0
+
+
+class WanTextEncoder(torch.nn.Module):
+    """Seam for the umT5-xxl encoder (utils/wan_wrapper.py:15-51).  Pass `encode_fn(prompts) -> [B, 512, 4096]`; the
+    padding rows must already be zero (wan_wrapper.py:46-47)."""
+
+    def __init__(self, encode_fn=None):
+        super().__init__()
+        self.encode_fn = encode_fn
+
+    def forward(self, text_prompts: List[str]) -> dict:
+        if self.encode_fn is None:
+            raise NotImplementedError("umT5-xxl is not part of this round's hot path; pass encode_fn or precomputed embeddings")
+        return {"prompt_embeds": self.encode_fn(text_prompts)}
+
+
+class SyntheticTextEncoder(WanTextEncoder):
+    """Deterministic stand-in used by tests / bench: a prompt hashes to a seed for N(0,1) embeddings, pad rows zeroed."""
+
+    def __init__(self, text_dim=4096, device="cuda:0", n_valid=64):
+        super().__init__(None)
+        self.text_dim, self.dev, self.n_valid = text_dim, device, n_valid
+
+    def forward(self, text_prompts: List[str]) -> dict:
+        import zlib
+        from .synthetic import philox_normal
+        outs = []
+        for p in text_prompts:
+            e = philox_normal([512, self.text_dim], zlib.crc32(p.encode("utf-8")))
+            e[self.n_valid:] = 0
+            outs.append(e)
+        return {"prompt_embeds": torch.stack(outs).to(self.dev)}
+
+
+class WanVAEWrapper(torch.nn.Module):
+    """utils/wan_wrapper.py:54-113 on the HIP Wan 3D-VAE engine (mmpl_amd/vae.py)."""
+
+    mean = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508,
+            0.4134, -0.0715, 0.5517, -0.3632, -0.1922, -0.9497, 0.2503, -0.2921]
+    std = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743,
+           3.2687, 2.1526, 2.8652, 1.5579, 1.6382, 1.1253, 2.8251, 1.9160]
+
+    def __init__(self, geometry: Optional[Geometry] = None, device="cuda:0", state_dict: Optional[dict] = None,
+                 pretrained_path: Optional[str] = None):
+        super().__init__()
+        from .vae import VaeEngine
+        self.geometry = geometry or Geometry.named("480p")
+        self.model = VaeEngine(self.geometry.lat_h, self.geometry.lat_w, device)
+        path = pretrained_path or f"{local_wan_path}/Wan2.1-T2V-14B/Wan2.1_VAE.pth"
+        if state_dict is None and os.path.exists(path):
+            state_dict = torch.load(path, map_location="cpu")
+        if state_dict is not None:
+            self.model.load_state_dict(state_dict)
+
+    def to(self, *args, **kwargs):
+        return self
+
+    def encode_to_latent(self, pixel: torch.Tensor) -> torch.Tensor:
+        """pixel [B, 3, T, H, W] in [-1, 1] -> latent [B, F, 16, h, w] float32 (normalised mu)."""
+        return torch.stack([self.model.encode(u, self.mean, self.std).float() for u in pixel], dim=0)
+
+    def decode_to_pixel(self, latent: torch.Tensor, use_cache: bool = False) -> torch.Tensor:
+        """latent [B, F, 16, h, w] -> pixel [B, T, 3, 8h, 8w] float32 clamped to [-1, 1]."""
+        return torch.stack([self.model.decode(u, self.mean, self.std).float().clamp_(-1, 1) for u in latent], dim=0)

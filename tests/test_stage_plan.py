@@ -1,0 +1,55 @@
+"""Host logic: stage schedule, slot map, visibility evolution, algorithmic-FLOP table (known answers from
+SURVEY.md Appendix A / BASELINE.md section 3)."""
+import pytest
+
+from mmpl_amd.stage_plan import (T2V_STAGE_SHAPES, StagePlan, VisibleFrames, dit_forward_flops, slot_of)
+from mmpl_amd.synthetic import WAN_CONFIGS
+from oracle import stage_ref
+
+
+def test_t2v_stage_tables():
+    p = StagePlan("t2v")
+    assert p.stages == [[0, 1], [2, 3, 10, 11, 12, 19, 20], [4, 5, 6, 7, 8, 9], [13, 14, 15, 16, 17, 18]]
+    assert p.handoff_stage == 1
+    assert p.write_slots(p.stages[1]) == [2, 3, 10, 11, 12, 13, 14]
+    assert p.write_slots(p.stages[3]) == [-1] * 6
+    assert p.renoised_frames(2) == [4, 9] and p.renoised_frames(3) == [13, 18] and p.renoised_frames(1) == []
+    assert p.stages == stage_ref.stage_frames(stage_ref.T2V_CLEAN_STEPS)
+
+
+def test_i2v_stage_tables():
+    p = StagePlan("i2v")
+    assert p.stages == [[0], [1], [2, 3, 10, 11, 12, 19, 20], [4, 5, 6, 7, 8, 9], [13, 14, 15, 16, 17, 18]]
+    assert p.handoff_stage == 2 and not p.hides_anchors(3) and p.renoised_frames(3) == []
+
+
+def test_slot_map():
+    assert [slot_of(f) for f in (0, 12, 19, 20)] == [0, 12, 13, 14]
+    assert max(slot_of(f) for f in range(21) if f not in range(13, 19)) == 14
+
+
+def test_visibility_evolution_matches_oracle_and_appendix_a():
+    p = StagePlan("t2v")
+    v, o = VisibleFrames(), stage_ref.VisIndex()
+    lkv = []
+    for si, frames in enumerate(p.stages):
+        if p.hides_anchors(si):
+            v.hide(); o.hide()
+        if p.shows_anchors(si):
+            v.show(); o.show()
+        v.on_forward(frames); o.on_forward(frames)
+        assert v.slots() == o.slots()
+        own = 0 if p.write_slots(frames)[0] >= 0 else len(frames)
+        lkv.append(len(v.slots()) + own)
+    assert lkv == [2, 9, 13, 21]
+    assert [(len(f), k) for f, k in zip(p.stages, lkv)] == T2V_STAGE_SHAPES
+    assert v.token_offsets(1560)[-2:] == [31200, 29640] or sorted(v.token_offsets(1560))[-2:] == [29640, 31200]
+
+
+@pytest.mark.parametrize("model,S,expect_tf", [("14B", 3600, [217.62, 1281.90, 1353.58, 1863.18]),
+                                               ("14B", 1560, [83.87, 391.25, 383.20, 478.89]),
+                                               ("1.3B", 1560, [9.89, 56.60, 59.28, 80.81])])
+def test_flop_table_known_answers(model, S, expect_tf):
+    got = [dit_forward_flops(WAN_CONFIGS[model], S, q, kv) / 1e12 for q, kv in T2V_STAGE_SHAPES]
+    for g, e in zip(got, expect_tf):
+        assert abs(g - e) / e < 2e-3, (got, expect_tf)
