@@ -97,6 +97,24 @@ typedef struct MmplUniPCStep {
 int mmpl_cfg_unipc_step(const void* flow_cond, const void* flow_uncond, void* x, void* m0, void* m1, void* last_sample,
                         size_t n, const MmplUniPCStep* s, mmpl_stream_t stream);
 
+/* ---- Wan 3D causal VAE (wan/modules/vae.py:483-569 behind WanVAEWrapper, utils/wan_wrapper.py:54-113) ----
+ * Weights: mmpl_vae_num_weights() dev pointers in the reference state_dict order (mmpl_vae_weight_name(i)); conv weights
+ * repacked host-side to [Cout, taps * Cin] (Cin contiguous; Cin 3/16 zero-padded to 32, decoder.head Cout 3 -> 4).
+ * mode 0 = decode, 1 = encode.  mean / inv_std: host float[16] (bf16-rounded values of the wrapper's scale tensors). */
+typedef struct MmplVae MmplVae;
+int mmpl_vae_num_weights(void);
+const char* mmpl_vae_weight_name(int i);
+int mmpl_vae_create(int lat_h, int lat_w, MmplVae** out);
+void mmpl_vae_destroy(MmplVae* v);
+int mmpl_vae_bind_weights(MmplVae* v, const void* const* dev_ptrs, int n);
+size_t mmpl_vae_workspace_bytes(MmplVae* v, int mode);
+/* WanVAE_.decode: z dev bf16 [n_frames, 16, lat_h, lat_w] -> out dev float32 [1 + 4(n_frames-1), 3, 8 lat_h, 8 lat_w], clamped */
+int mmpl_vae_decode(MmplVae* v, const void* z, int n_frames, const float* mean, const float* inv_std, void* out, void* workspace,
+                    size_t workspace_bytes, mmpl_stream_t stream);
+/* WanVAE_.encode: px dev bf16 [3, n_px_frames = 1 + 4k, 8 lat_h, 8 lat_w] -> out dev float32 [1 + k, 16, lat_h, lat_w] (normalised mu) */
+int mmpl_vae_encode(MmplVae* v, const void* px, int n_px_frames, const float* mean, const float* inv_std, void* out, void* workspace,
+                    size_t workspace_bytes, mmpl_stream_t stream);
+
 /* Optional per-kernel-class hipEvent timing (bench.py's live roofline numbers; off by default, not thread-safe).
  * kinds: 0 gemm, 1 self-attention, 2 cross-attention, 3 layernorm, 4 qk-norm/rope/kv-write, 5 elementwise, 6 cfg+unipc,
  * 7 vae.  mmpl_profile_read synchronises the device, sums the event pairs recorded since enable/last read. */

@@ -12,6 +12,8 @@ SYMBOLS = [
     "mmpl_dit_num_weights", "mmpl_dit_weight_name", "mmpl_dit_create", "mmpl_dit_destroy", "mmpl_dit_bind_weights",
     "mmpl_dit_workspace_bytes", "mmpl_dit_context_workspace_bytes", "mmpl_dit_precompute_context", "mmpl_dit_forward",
     "mmpl_attn_fwd", "mmpl_gemm", "mmpl_layernorm", "mmpl_qknorm_rope", "mmpl_cfg_unipc_step",
+    "mmpl_vae_num_weights", "mmpl_vae_weight_name", "mmpl_vae_create", "mmpl_vae_destroy", "mmpl_vae_bind_weights",
+    "mmpl_vae_workspace_bytes", "mmpl_vae_decode", "mmpl_vae_encode",
     "mmpl_profile_enable", "mmpl_profile_read", "mmpl_last_error", "mmpl_version",
 ]
 
@@ -74,14 +76,17 @@ def load() -> C.CDLL:
 
 def _bind_vae(lib):
     vp, ci, sz = C.c_void_p, C.c_int, C.c_size_t
+    fp = C.POINTER(C.c_float)
+    lib.mmpl_vae_weight_name.argtypes = [ci]
+    lib.mmpl_vae_weight_name.restype = C.c_char_p
     lib.mmpl_vae_create.argtypes = [ci, ci, C.POINTER(vp)]
     lib.mmpl_vae_destroy.argtypes = [vp]
     lib.mmpl_vae_destroy.restype = None
     lib.mmpl_vae_bind_weights.argtypes = [vp, C.POINTER(vp), ci]
     lib.mmpl_vae_workspace_bytes.argtypes = [vp, ci]
     lib.mmpl_vae_workspace_bytes.restype = sz
-    lib.mmpl_vae_decode.argtypes = [vp, vp, ci, vp, vp, sz, vp]
-    lib.mmpl_vae_encode.argtypes = [vp, vp, ci, vp, vp, sz, vp]
+    lib.mmpl_vae_decode.argtypes = [vp, vp, ci, fp, fp, vp, vp, sz, vp]
+    lib.mmpl_vae_encode.argtypes = [vp, vp, ci, fp, fp, vp, vp, sz, vp]
 
 
 def check(rc: int, what: str = "") -> None:

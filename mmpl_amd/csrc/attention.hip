@@ -140,19 +140,23 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f((m_run - m_new) * c);
-    m_run = m_new;
-    const float mc = m_new * c;
-    float ls = 0.f;
+    // exact lazy rescale: only when some row's running max actually grew (rare after the first tiles)
+    if (__any(m_new > m_run)) {
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      l_run *= alpha;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s0[r] = exp2f(s0[r] * c - mc); ls += s0[r]; }
+      for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s1[r] = exp2f(s1[r] * c - mc); ls += s1[r]; }
-    l_run = l_run * alpha + ls;
+        for (int r = 0; r < 16; ++r) o[nb][r] *= alpha;
+      m_run = m_new;
+    }
+    const float mc = m_run * c;
+    float ls0 = 0.f, ls1 = 0.f;
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
+    for (int r = 0; r < 16; ++r) { s0[r] = __builtin_amdgcn_exp2f(s0[r] * c - mc); ls0 += s0[r]; }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[nb][r] *= alpha;
+    for (int r = 0; r < 16; ++r) { s1[r] = __builtin_amdgcn_exp2f(s1[r] * c - mc); ls1 += s1[r]; }
+    l_run += ls0 + ls1;
 
     // ---- P^T fragments: chunk (half, cc) = registers 8cc..8cc+7 packed to bf16
     bf16x8 pb[2][2];

@@ -14,15 +14,15 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 #define MMPL_DEV __device__ __forceinline__
 
 MMPL_DEV float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even fp32 -> bf16 (same rounding as PyTorch's c10::BFloat16)
-MMPL_DEV bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;  // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// round-to-nearest-even fp32 -> bf16 (same rounding as PyTorch's c10::BFloat16); gfx950 has the hardware
+// conversion v_cvt_pk_bf16_f32, which the compiler emits for these casts.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16v2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+MMPL_DEV uint32_t pack2bf(float lo, float hi) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){lo, hi}, bf16v2_t));
 }
+MMPL_DEV bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 MMPL_DEV float rbf(float f) { return bf2f(f2bf(f)); }  // round through bf16
-MMPL_DEV uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 
 MMPL_DEV float gelu_tanh(float x) {
   // torch GELU(approximate='tanh'): 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3)))

@@ -133,6 +133,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + 64 * wn + 16 * j + 4 * fchunk;
       if (n >= g.N) continue;  // N is a multiple of 4 for every caller
+      if (EPI == EPI_F32_SCALE) {
+        f32x4 o4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o4[r] = acc[i][j][r] * g.alpha;
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (size_t)m * g.ldc + n) = o4;
+        continue;
+      }
       float v[4];
       {
         float b[4] = {0.f, 0.f, 0.f, 0.f};
@@ -195,6 +202,7 @@ hipError_t mmpl_launch_gemm(const GemmArgs& g, hipStream_t s) {
     case EPI_BIAS_SILU: return launch<EPI_BIAS_SILU>(g, s);
     case EPI_GATE_RES: return launch<EPI_GATE_RES>(g, s);
     case EPI_RES: return launch<EPI_RES>(g, s);
+    case EPI_F32_SCALE: return launch<EPI_F32_SCALE>(g, s);
   }
   return hipErrorInvalidValue;
 }

@@ -5,7 +5,7 @@
 #include "common.h"
 
 // ---------------------------------------------------------------- GEMM (gemm.hip)
-enum GemmEpi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_SILU = 2, EPI_GATE_RES = 3, EPI_RES = 4 };
+enum GemmEpi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_SILU = 2, EPI_GATE_RES = 3, EPI_RES = 4, EPI_F32_SCALE = 5 };
 struct GemmArgs {
   const bf16_t* A; int lda;      // [M, K]
   const bf16_t* W; int ldw;      // [N, K]  (nn.Linear weight)
@@ -17,6 +17,7 @@ struct GemmArgs {
   const bf16_t* gate;            // per-frame gate vectors: gate[frame * gate_frame_stride + n]
   int gate_frame_stride;
   int rows_per_frame;
+  float alpha;                   // EPI_F32_SCALE: C is float*, C = alpha * acc (no bias)
 };
 hipError_t mmpl_launch_gemm(const GemmArgs& g, hipStream_t s);
 

@@ -78,3 +78,93 @@ def philox_normal(shape, seed: int, dtype=torch.bfloat16) -> torch.Tensor:
     for s in shape:
         n *= int(s)
     return torch.from_numpy(rng.standard_normal(n, dtype=np.float32)).reshape(*shape).to(dtype)
+
+
+# ---------------------------------------------------------------------------------------------- Wan 3D-VAE weights
+VAE_DIM, VAE_Z, VAE_DIM_MULT, VAE_T_DOWN = 96, 16, [1, 2, 4, 4], [False, True, True]
+
+
+def vae_layout():
+    """(key, shape) of every tensor of `WanVAE_(dim=96, z_dim=16, ...)` (MMPL_t2v/wan/modules/vae.py:612-636), in
+    state_dict order.  Derived from the constructor logic (vae.py:284-316, 388-421), not from a checkpoint."""
+    out = []
+
+    def conv3(name, cout, cin, k):
+        out.append((name + ".weight", (cout, cin) + tuple(k)))
+        out.append((name + ".bias", (cout,)))
+
+    def res(pre, cin, cout):
+        out.append((pre + "residual.0.gamma", (cin, 1, 1, 1)))
+        conv3(pre + "residual.2", cout, cin, (3, 3, 3))
+        out.append((pre + "residual.3.gamma", (cout, 1, 1, 1)))
+        conv3(pre + "residual.6", cout, cout, (3, 3, 3))
+        if cin != cout:
+            conv3(pre + "shortcut", cout, cin, (1, 1, 1))
+
+    def attn(pre, c):
+        out.append((pre + "norm.gamma", (c, 1, 1)))
+        conv3(pre + "to_qkv", 3 * c, c, (1, 1))
+        conv3(pre + "proj", c, c, (1, 1))
+
+    # encoder
+    dims = [VAE_DIM * u for u in [1] + VAE_DIM_MULT]
+    conv3("encoder.conv1", dims[0], 3, (3, 3, 3))
+    j = 0
+    for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+        for _ in range(2):
+            res(f"encoder.downsamples.{j}.", cin, cout)
+            cin = cout
+            j += 1
+        if i != len(VAE_DIM_MULT) - 1:
+            conv3(f"encoder.downsamples.{j}.resample.1", cout, cout, (3, 3))
+            if VAE_T_DOWN[i]:
+                conv3(f"encoder.downsamples.{j}.time_conv", cout, cout, (3, 1, 1))
+            j += 1
+    res("encoder.middle.0.", dims[-1], dims[-1])
+    attn("encoder.middle.1.", dims[-1])
+    res("encoder.middle.2.", dims[-1], dims[-1])
+    out.append(("encoder.head.0.gamma", (dims[-1], 1, 1, 1)))
+    conv3("encoder.head.2", 2 * VAE_Z, dims[-1], (3, 3, 3))
+    conv3("conv1", 2 * VAE_Z, 2 * VAE_Z, (1, 1, 1))
+    conv3("conv2", VAE_Z, VAE_Z, (1, 1, 1))
+    # decoder
+    dims = [VAE_DIM * u for u in [VAE_DIM_MULT[-1]] + VAE_DIM_MULT[::-1]]
+    t_up = VAE_T_DOWN[::-1]
+    conv3("decoder.conv1", dims[0], VAE_Z, (3, 3, 3))
+    res("decoder.middle.0.", dims[0], dims[0])
+    attn("decoder.middle.1.", dims[0])
+    res("decoder.middle.2.", dims[0], dims[0])
+    j = 0
+    for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+        if i in (1, 2, 3):
+            cin = cin // 2
+        for _ in range(3):
+            res(f"decoder.upsamples.{j}.", cin, cout)
+            cin = cout
+            j += 1
+        if i != len(VAE_DIM_MULT) - 1:
+            conv3(f"decoder.upsamples.{j}.resample.1", cout // 2, cout, (3, 3))
+            if t_up[i]:
+                conv3(f"decoder.upsamples.{j}.time_conv", cout * 2, cout, (3, 1, 1))
+            j += 1
+    out.append(("decoder.head.0.gamma", (dims[-1], 1, 1, 1)))
+    conv3("decoder.head.2", 3, dims[-1], (3, 3, 3))
+    return out
+
+
+def vae_state_dict(seed: int = 0, dtype=torch.bfloat16, device="cpu") -> "OrderedDict[str, torch.Tensor]":
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for name, shape in vae_layout():
+        if name.endswith(".gamma"):
+            t = 1 + 0.1 * torch.randn(*shape, generator=g, device=device)
+        elif name.endswith(".bias"):
+            t = 0.02 * torch.randn(*shape, generator=g, device=device)
+        else:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            t = torch.randn(*shape, generator=g, device=device) * (1.0 / math.sqrt(fan_in))
+        sd[name] = t.to(dtype)
+    return sd

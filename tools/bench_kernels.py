@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the two MFMA kernels on the 14B/720p shapes (dev tool).
+    python tools/bench_kernels.py attn|gemm|all [--iters N]"""
+import ctypes as C
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mmpl_amd import _lib  # noqa: E402
+
+lib = _lib.load()
+dev = "cuda:0"
+BF = torch.bfloat16
+
+
+def timeit(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def bench_attn(iters):
+    H, S, d = 40, 3600, 5120
+    n_slots = 21
+    kc = torch.randn(n_slots * S, d, device=dev).to(BF)
+    vc = torch.randn(n_slots * S, d, device=dev).to(BF)
+    for name, nq, npg in (("s0", 2, 2), ("s1", 7, 9), ("s2", 6, 13), ("s3", 6, 21), ("cross", 7, 0)):
+        Lq = nq * S
+        q = torch.randn(Lq, 3 * d, device=dev).to(BF)
+        o = torch.empty(Lq, d, device=dev, dtype=BF)
+        if npg == 0:
+            pr, npg_ = 512, 1
+        else:
+            pr, npg_ = S, npg
+        kp = (C.c_void_p * npg_)(*[kc[i * S:].data_ptr() for i in range(npg_)])
+        vp = (C.c_void_p * npg_)(*[vc[i * S:].data_ptr() for i in range(npg_)])
+        fn = lambda: _lib.check(lib.mmpl_attn_fwd(_lib.ptr(q), 3 * d, _lib.ptr(o), d, kp, vp, d, d, npg_, pr, Lq, H,
+                                                  1 / math.sqrt(128), _lib.stream_ptr()))
+        ms = timeit(fn, iters)
+        fl = 4.0 * Lq * npg_ * pr * d
+        print(f"attn {name}: Lq={Lq} Lkv={npg_ * pr}  {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s", flush=True)
+
+
+def bench_gemm(iters):
+    for name, M, N, K, epi in (("qkv", 25200, 15360, 5120, 0), ("o", 25200, 5120, 5120, 3), ("ffn0", 25200, 13824, 5120, 1),
+                               ("ffn2", 25200, 5120, 13824, 3), ("qkv_s0", 7200, 15360, 5120, 0), ("sq8k", 8192, 8192, 8192, 0)):
+        A = torch.randn(M, K, device=dev).to(BF)
+        W = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(BF)
+        b = torch.randn(N, device=dev).to(BF)
+        Cc = torch.empty(M, N, device=dev, dtype=BF)
+        res = torch.randn(M, N, device=dev).to(BF)
+        gate = torch.randn(8, N, device=dev).to(BF)
+        fn = lambda: _lib.check(lib.mmpl_gemm(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(Cc), N, M, N, K, epi, _lib.ptr(res),
+                                              N, _lib.ptr(gate), N, 3600, _lib.stream_ptr()))
+        ms = timeit(fn, iters)
+        print(f"gemm {name}: M={M} N={N} K={K} epi={epi}  {ms:8.3f} ms  {2.0 * M * N * K / ms / 1e9:8.1f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 5
+    if what in ("attn", "all"):
+        bench_attn(iters)
+    if what in ("gemm", "all"):
+        bench_gemm(iters)
