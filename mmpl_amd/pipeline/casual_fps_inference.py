@@ -58,6 +58,7 @@ class CausalFPSInferencePipeline(torch.nn.Module):
         self.independent_first_frame = args.independent_first_frame
         self.local_attn_size = -1
         self.handoff_sink: Optional[Callable[[torch.Tensor], None]] = None
+        self.renoise_override = None      # tests: {frame: [1,16,h,w]} instead of torch.randn_like draws
 
         # ---- "add new noise on previous frames" schedule (casual_fps_inference.py:93-108); the randint keeps the
         # reference's RNG consumption order; the resulting timestep is >= 1000, i.e. pure noise
@@ -131,8 +132,10 @@ class CausalFPSInferencePipeline(torch.nn.Module):
                     src = (3, 10) if si == 2 else (12, 19)
                     for pos, s in ((0, src[0]), (-1, src[1])):
                         sl = slice(0, 1) if pos == 0 else slice(-1, None)
+                        fresh = (torch.randn_like(latents[:, sl]) if self.renoise_override is None else
+                                 self.renoise_override[frames[pos]].to(latents).unsqueeze(1))
                         latents[:, sl] = self.ddpm_scheduler.add_noise(
-                            output[:, s:s + 1].flatten(0, 1), torch.randn_like(latents[:, sl]).flatten(0, 1),
+                            output[:, s:s + 1].flatten(0, 1), fresh.flatten(0, 1),
                             self.ddmp_timestep.flatten(0, 1)).unflatten(0, (1, 1))
                 if self.plan.hides_anchors(si):
                     for cache in (self.kv_cache_pos, self.kv_cache_neg):

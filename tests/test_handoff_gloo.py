@@ -1,0 +1,81 @@
+"""N>1 path on CPU: the chunk wavefront + anchor hand-off over torch.distributed (gloo, world_size 2)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mmpl_amd.handoff import ChunkHandoff, run_chunk_wavefront, stitch_chunks
+
+SHAPE = (1, 8, 16, 6, 10)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_chunks, fail_at, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    ho = ChunkHandoff(SHAPE, "cpu")
+    log = []
+
+    def make_chunk(c, initial, sink):
+        # chunk c's "anchors" are a deterministic function of c and of what it received (chains the dependency)
+        base = torch.full(SHAPE, float(c + 1), dtype=torch.bfloat16)
+        if initial is not None:
+            base = base + initial.float().mean().to(torch.bfloat16)
+        if c == fail_at:
+            raise ValueError("boom")
+        sink(base)
+        log.append((c, None if initial is None else float(initial.float().mean())))
+        return base[:, :2].clone()
+
+    try:
+        res = run_chunk_wavefront(make_chunk, n_chunks, ho, to_initial=lambda t: t[:, :2])
+        torch.save({"rank": rank, "log": log, "res": res, "err": None}, f"{out_path}.{rank}")
+    except Exception as e:
+        torch.save({"rank": rank, "log": log, "res": None, "err": repr(e)}, f"{out_path}.{rank}")
+        import time
+        time.sleep(3)          # let the FAILED header drain before this rank tears its sockets down
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(tmp_path, n_chunks, fail_at=-1, world=2):
+    out = str(tmp_path / "out")
+    mp.spawn(_worker, args=(world, _free_port(), n_chunks, fail_at, out), nprocs=world, join=True)
+    return [torch.load(f"{out}.{r}") for r in range(world)]
+
+
+def test_wavefront_five_chunks_two_ranks(tmp_path):
+    r0, r1 = _run(tmp_path, 5)
+    assert r0["err"] is None and r1["err"] is None
+    assert [c for c, _ in r0["log"]] == [0, 2, 4] and [c for c, _ in r1["log"]] == [1, 3]
+    # chained values: v0 = 1, v1 = 2 + 1 = 3, v2 = 3 + 3 = 6, v3 = 4 + 6 = 10, v4 = 5 + 10 = 15
+    assert [v for _, v in r0["log"]] == [None, 3.0, 10.0] and [v for _, v in r1["log"]] == [1.0, 6.0]
+    res = r0["res"]
+    assert r1["res"] is None and len(res) == 5
+    assert [float(t.float().mean()) for t in res] == [1.0, 3.0, 6.0, 10.0, 15.0]
+
+
+def test_producer_failure_propagates_instead_of_hanging(tmp_path):
+    r0, r1 = _run(tmp_path, 4, fail_at=1)
+    assert "boom" in r1["err"]                    # chunk 1 (rank 1) failed ...
+    # ... and chunk 2's consumer (rank 0) raised instead of spinning: normally via the FAILED status header, or via the
+    # transport error if the producer's sockets were already gone
+    assert r0["err"] is not None and ("status -1" in r0["err"] or "rror" in r0["err"])
+
+
+def test_stitch_chunks_drops_five_overlap_frames():
+    v = [torch.arange(81).view(1, 81, 1).float() + 100 * i for i in range(3)]
+    s = stitch_chunks(v)
+    assert s.shape[1] == 81 + 76 + 76 and s[0, 81, 0] == 105 and s[0, 80, 0] == 80
