@@ -113,6 +113,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs a) {
     f32x16 s0, s1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
       const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kb + k_off + 32 * cc);
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs a) {
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[cc], s0, 0, 0, 0);
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[cc], s1, 0, 0, 0);
     }
+    __builtin_amdgcn_s_setprio(0);
     // lane holds kv_local = 32*half + 8*(r>>2) + 4*hi + (r&3) for its query column
     {
       const int p = t / tiles_pp, row0 = (t - p * tiles_pp) * KVB;
@@ -173,6 +175,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs a) {
     }
 
     // ---- O^T += V^T . P^T : A operand element j of lane (d, hi) is V[32*half + 16*cc + 8*(j>>2) + 4*hi + (j&3)][d]
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
 #pragma unroll
@@ -185,6 +188,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs a) {
         }
       }
     }
+    __builtin_amdgcn_s_setprio(0);
 
     if (t + 1 < total) stage_write(cur ^ 1);
     __syncthreads();

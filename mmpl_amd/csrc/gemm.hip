@@ -8,6 +8,8 @@
 // current tile's MFMAs; one barrier per K tile.  The MFMA is issued "swapped" (W fragment as the A
 // operand) so each lane ends up with 4 consecutive output columns -> 8-byte epilogue loads/stores.
 // Rounding points of the epilogues follow the reference's bf16 module boundaries (DESIGN.md "numerics").
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -15,6 +17,65 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+
+// Shared epilogue: wave tile 64x64 at (mw, nw); lane holds, per fragment (i,j), column m = ..+(lane&15) and rows
+// n = ..+4*(lane>>4)+{0..3} (the MFMA is issued with the W fragment as the A operand).
+template <int EPI>
+MMPL_DEV void gemm_epilogue(const GemmArgs& g, const f32x4 (&acc)[4][4], int mw, int nw, int frow, int fchunk) {
+  const int m0 = 0, n0 = 0, wm = 0, wn = 0;
+  (void)m0; (void)n0; (void)wm; (void)wn;
+  // ---- epilogue: lane holds, per fragment (i,j), column m = ..+(lane&15) and rows n = ..+4*(lane>>4)+{0..3}
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = mw + 16 * i + frow;
+    if (m >= g.M) continue;
+    const int frame = (EPI == EPI_GATE_RES) ? (m / g.rows_per_frame) : 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = nw + 16 * j + 4 * fchunk;
+      if (n >= g.N) continue;  // N is a multiple of 4 for every caller
+      if (EPI == EPI_F32_SCALE) {
+        f32x4 o4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o4[r] = acc[i][j][r] * g.alpha;
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (size_t)m * g.ldc + n) = o4;
+        continue;
+      }
+      float v[4];
+      {
+        float b[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) {
+          const uint2 bb = *reinterpret_cast<const uint2*>(g.bias + n);
+          b[0] = bf2f(bb.x & 0xffff); b[1] = bf2f(bb.x >> 16); b[2] = bf2f(bb.y & 0xffff); b[3] = bf2f(bb.y >> 16);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rbf(acc[i][j][r] + b[r]);  // Linear output rounds to bf16
+      }
+      if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
+      } else if (EPI == EPI_BIAS_SILU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = silu(v[r]);
+      } else if (EPI == EPI_GATE_RES || EPI == EPI_RES) {
+        const uint2 xx = *reinterpret_cast<const uint2*>(g.res + (size_t)m * g.ldres + n);
+        float x[4] = {bf2f(xx.x & 0xffff), bf2f(xx.x >> 16), bf2f(xx.y & 0xffff), bf2f(xx.y >> 16)};
+        if (EPI == EPI_GATE_RES) {
+          const uint2 ee = *reinterpret_cast<const uint2*>(g.gate + (size_t)frame * g.gate_frame_stride + n);
+          float e[4] = {bf2f(ee.x & 0xffff), bf2f(ee.x >> 16), bf2f(ee.y & 0xffff), bf2f(ee.y >> 16)};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = rbf(v[r] * e[r]);  // y * e rounds, then x + (.) rounds
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = x[r] + v[r];
+      }
+      uint2 o;
+      o.x = pack2bf(v[0], v[1]);
+      o.y = pack2bf(v[2], v[3]);
+      *reinterpret_cast<uint2*>(g.C + (size_t)m * g.ldc + n) = o;
+    }
+  }
+}
 
 template <int EPI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel(GemmArgs g) {
@@ -123,61 +184,244 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds, per fragment (i,j), column m = ..+(lane&15) and rows n = ..+4*(lane>>4)+{0..3}
+  gemm_epilogue<EPI>(g, acc, m0 + 64 * wm, n0 + 64 * wn, frow, fchunk);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// v2: 256x128x64 tile, 512 threads = 8 waves (4x2, 64x64 each).  Operands go global -> LDS directly
+// (global_load_lds_dwordx4, no VGPR staging) into a 3-deep LDS ring, so the loads of tile t+2 are in flight while
+// tile t is multiplied; the ring is ordered with a COUNTED s_waitcnt vmcnt(6) (6 LDS-DMA instructions per wave per
+// tile) + a raw s_barrier -- never __syncthreads(), which would drain the DMA queue.  LDS image is lane-linear, so
+// the XOR swizzle is applied to the per-lane SOURCE chunk and again on the fragment read (same involution).
+constexpr int BM2 = 256, BN2 = 128;
+constexpr int A2_BYTES = BM2 * BK * 2, W2_BYTES = BN2 * BK * 2, STAGE2 = A2_BYTES + W2_BYTES, NSTAGE2 = 3;
+
+MMPL_DEV void glds16(const void* g, char* lds) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_v2_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tiles_m = (g.M + BM2 - 1) / BM2, tiles_n = (g.N + BN2 - 1) / BN2;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  constexpr int GROUP = 4;
+  const int per_group = GROUP * tiles_n;
+  const int gid = bid / per_group;
+  const int first_m = gid * GROUP;
+  const int gsz = min(tiles_m - first_m, GROUP);
+  const int tm = first_m + (bid % per_group) % gsz;
+  const int tn = (bid % per_group) / gsz;
+  const int m0 = tm * BM2, n0 = tn * BN2;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // per-lane DMA sources: LDS chunk p (16 B) of a tile holds global chunk (p&7)^(row&7) of row p>>3
+  const bf16_t* a_src[4];
+  const bf16_t* w_src[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = (j * 8 + wave) * 64 + lane, row = p >> 3, c = (p & 7) ^ (row & 7);
+    a_src[j] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + c * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int p = (j * 8 + wave) * 64 + lane, row = p >> 3, c = (p & 7) ^ (row & 7);
+    w_src[j] = g.W + (size_t)min(n0 + row, g.N - 1) * g.ldw + c * 8;
+  }
+  auto issue = [&](int t) {
+    char* st = smem + (t % NSTAGE2) * STAGE2;
+    const int koff = t * BK;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16(a_src[j] + koff, st + (j * 8 + wave) * 1024);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) glds16(w_src[j] + koff, st + A2_BYTES + (j * 8 + wave) * 1024);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fchunk = lane >> 4;
+  int a_off[4], w_off[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int m = m0 + 64 * wm + 16 * i + frow;
-    if (m >= g.M) continue;
-    const int frame = (EPI == EPI_GATE_RES) ? (m / g.rows_per_frame) : 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + 64 * wn + 16 * j + 4 * fchunk;
-      if (n >= g.N) continue;  // N is a multiple of 4 for every caller
-      if (EPI == EPI_F32_SCALE) {
-        f32x4 o4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o4[r] = acc[i][j][r] * g.alpha;
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (size_t)m * g.ldc + n) = o4;
-        continue;
-      }
-      float v[4];
-      {
-        float b[4] = {0.f, 0.f, 0.f, 0.f};
-        if (g.bias) {
-          const uint2 bb = *reinterpret_cast<const uint2*>(g.bias + n);
-          b[0] = bf2f(bb.x & 0xffff); b[1] = bf2f(bb.x >> 16); b[2] = bf2f(bb.y & 0xffff); b[3] = bf2f(bb.y >> 16);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = rbf(acc[i][j][r] + b[r]);  // Linear output rounds to bf16
-      }
-      if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
-      } else if (EPI == EPI_BIAS_SILU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = silu(v[r]);
-      } else if (EPI == EPI_GATE_RES || EPI == EPI_RES) {
-        const uint2 xx = *reinterpret_cast<const uint2*>(g.res + (size_t)m * g.ldres + n);
-        float x[4] = {bf2f(xx.x & 0xffff), bf2f(xx.x >> 16), bf2f(xx.y & 0xffff), bf2f(xx.y >> 16)};
-        if (EPI == EPI_GATE_RES) {
-          const uint2 ee = *reinterpret_cast<const uint2*>(g.gate + (size_t)frame * g.gate_frame_stride + n);
-          float e[4] = {bf2f(ee.x & 0xffff), bf2f(ee.x >> 16), bf2f(ee.y & 0xffff), bf2f(ee.y >> 16)};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = rbf(v[r] * e[r]);  // y * e rounds, then x + (.) rounds
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = x[r] + v[r];
-      }
-      uint2 o;
-      o.x = pack2bf(v[0], v[1]);
-      o.y = pack2bf(v[2], v[3]);
-      *reinterpret_cast<uint2*>(g.C + (size_t)m * g.ldc + n) = o;
-    }
+    const int ar = 64 * wm + 16 * i + frow, wr = 64 * wn + 16 * i + frow;
+    a_off[i] = ar * 128 + ((fchunk ^ (ar & 7)) << 4);
+    w_off[i] = A2_BYTES + wr * 128 + ((fchunk ^ (wr & 7)) << 4);
   }
+
+  const int nt = g.K / BK;
+  issue(0);
+  if (nt > 1) {
+    issue(1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+
+  for (int t = 0; t < nt; ++t) {
+    if (t + 2 < nt) issue(t + 2);
+    const char* st = smem + (t % NSTAGE2) * STAGE2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8*>(st + (a_off[i] ^ (ks << 6)));
+        wf[i] = *reinterpret_cast<const bf16x8*>(st + (w_off[i] ^ (ks << 6)));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    // tile t+1 must have landed (everything but the 6 newest DMA ops of this wave), then everyone syncs
+    if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  gemm_epilogue<EPI>(g, acc, m0 + 64 * wm, n0 + 64 * wn, frow, fchunk);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// v3: 256x256x32 tile, 8 waves (2x4), wave tile 128x64 (8x4 fragments, 128 accumulator VGPRs): 25 % fewer LDS
+// fragment reads per MFMA than a 64x64 wave tile, which is what bounds v2 (LDS ~70 % busy).  Same DMA ring as v2 but
+// BK = 32 so three 32 KiB stages fit: 4 LDS-DMA instructions per wave per tile -> s_waitcnt vmcnt(4).
+constexpr int BM3 = 256, BN3 = 256, BK3 = 32;
+constexpr int A3_BYTES = BM3 * BK3 * 2, STAGE3 = 2 * A3_BYTES, NSTAGE3 = 3;
+MMPL_DEV int swz32(int r, int c) { return r * 64 + ((c ^ ((0 - (r >> 2)) & 3)) << 4); }
+
+template <int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_v3_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tiles_m = (g.M + BM3 - 1) / BM3, tiles_n = (g.N + BN3 - 1) / BN3;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  constexpr int GROUP = 4;
+  const int per_group = GROUP * tiles_n;
+  const int gid = bid / per_group;
+  const int first_m = gid * GROUP;
+  const int gsz = min(tiles_m - first_m, GROUP);
+  const int tm = first_m + (bid % per_group) % gsz;
+  const int tn = (bid % per_group) / gsz;
+  const int m0 = tm * BM3, n0 = tn * BN3;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;   // 2 x 4 waves, 128 x 64 each
+
+  const bf16_t* a_src[2];
+  const bf16_t* w_src[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int p = (j * 8 + wave) * 64 + lane, row = p >> 2, c = (p & 3) ^ ((0 - (row >> 2)) & 3);
+    a_src[j] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + c * 8;
+    w_src[j] = g.W + (size_t)min(n0 + row, g.N - 1) * g.ldw + c * 8;
+  }
+  auto issue = [&](int t) {
+    char* st = smem + (t % NSTAGE3) * STAGE3;
+    const int koff = t * BK3;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) glds16(a_src[j] + koff, st + (j * 8 + wave) * 1024);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) glds16(w_src[j] + koff, st + A3_BYTES + (j * 8 + wave) * 1024);
+  };
+
+  f32x4 acc[2][4][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fchunk = lane >> 4;
+  int a_off[8], w_off[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a_off[i] = swz32(128 * wm + 16 * i + frow, fchunk);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w_off[i] = A3_BYTES + swz32(64 * wn + 16 * i + frow, fchunk);
+
+  const int nt = g.K / BK3;
+  issue(0);
+  if (nt > 1) {
+    issue(1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+
+  for (int t = 0; t < nt; ++t) {
+    if (t + 2 < nt) issue(t + 2);
+    const char* st = smem + (t % NSTAGE3) * STAGE3;
+    bf16x8 af[8], wf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + w_off[i]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + a_off[i]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i >> 2][i & 3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i >> 2][i & 3][j], 0, 0, 0);
+    if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  gemm_epilogue<EPI>(g, acc[0], m0 + 128 * wm, n0 + 64 * wn, frow, fchunk);
+  gemm_epilogue<EPI>(g, acc[1], m0 + 128 * wm + 64, n0 + 64 * wn, frow, fchunk);
+}
+
+template <int EPI>
+hipError_t launch_v2(const GemmArgs& g, hipStream_t s) {
+  static bool attr_set = false;
+  constexpr int smem = NSTAGE2 * STAGE2;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_v2_kernel<EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int tiles = ((g.M + BM2 - 1) / BM2) * ((g.N + BN2 - 1) / BN2);
+  hipLaunchKernelGGL(gemm_bf16_v2_kernel<EPI>, dim3(tiles), dim3(512), smem, s, g);
+  return hipGetLastError();
+}
+
+template <int EPI>
+hipError_t launch_v3(const GemmArgs& g, hipStream_t s) {
+  static bool attr_set = false;
+  constexpr int smem = NSTAGE3 * STAGE3;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_v3_kernel<EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int tiles = ((g.M + BM3 - 1) / BM3) * ((g.N + BN3 - 1) / BN3);
+  hipLaunchKernelGGL(gemm_bf16_v3_kernel<EPI>, dim3(tiles), dim3(512), smem, s, g);
+  return hipGetLastError();
 }
 
 template <int EPI>
 hipError_t launch(const GemmArgs& g, hipStream_t s) {
+  if (g.M >= 1024 && g.N >= 256 && g.K >= 128 && !getenv("MMPL_GEMM_V1") && !getenv("MMPL_GEMM_V2")) return launch_v3<EPI>(g, s);
+  if (g.M >= 1024 && g.N >= 128 && g.K >= 128 && !getenv("MMPL_GEMM_V1")) return launch_v2<EPI>(g, s);
   static bool attr_set = false;
   constexpr int smem = 4 * TILE_BYTES;
   if (!attr_set) {
