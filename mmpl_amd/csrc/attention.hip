@@ -12,6 +12,8 @@
 // "Swapped" formulation: S^T = K.Q^T and O^T = V^T.P^T with v_mfma_f32_32x32x16_bf16, so each lane owns one
 // query column: softmax statistics are lane-local (one cross-half shuffle per tile) and the P^T fragment for
 // the PV MFMA is just 8 consecutive accumulator registers packed to bf16 (no LDS round trip for P).
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -109,30 +111,50 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs a) {
     const char* kb = smem + cur * BUF;
     const char* vb = kb + K_TILE;
 
-    // ---- S^T = K . Q^T   (two 32-row kv halves)
+    // ---- S^T = K . Q^T, one 32-row kv half at a time so that the vector work on half 0 (mask, row max) issues in the
+    // shadow of half 1's MFMAs; likewise P.V of half 0 runs under the exponentials of half 1.
+    const int pg = t / tiles_pp, row0 = (t - pg * tiles_pp) * KVB;
+    const int valid = a.page_rows - row0;
     f32x16 s0, s1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int cc = 0; cc < 8; ++cc) {
-      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kb + k_off + 32 * cc);
-      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kb + k_off + 32 * K_STRIDE + 32 * cc);
-      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[cc], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[cc], s1, 0, 0, 0);
-    }
-    __builtin_amdgcn_s_setprio(0);
-    // lane holds kv_local = 32*half + 8*(r>>2) + 4*hi + (r&3) for its query column
+    // K fragments are read 4 ahead of the MFMA that consumes them (a rotating 4-deep register window): without this
+    // hipcc issues read -> wait -> MFMA one at a time and every MFMA eats a full LDS round trip
     {
-      const int p = t / tiles_pp, row0 = (t - p * tiles_pp) * KVB;
-      const int valid = a.page_rows - row0;
-      if (valid < KVB) {
+      auto kfrag = [&](int i) {  // i = 0..15: half = i >> 3, hd chunk = i & 7
+        return *reinterpret_cast<const bf16x8*>(kb + k_off + (i >> 3) * (32 * K_STRIDE) + 32 * (i & 7));
+      };
+      bf16x8 w0 = kfrag(0), w1 = kfrag(1), w2 = kfrag(2), w3 = kfrag(3);
+      __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise sinks each read down to its MFMA
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int kv = 8 * (r >> 2) + 4 * hi + (r & 3);
-          if (kv >= valid) s0[r] = -INFINITY;
-          if (kv + 32 >= valid) s1[r] = -INFINITY;
-        }
+      for (int i = 0; i < 16; i += 4) {
+        if (i < 8) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, qf[i & 7], s0, 0, 0, 0);
+        else s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, qf[i & 7], s1, 0, 0, 0);
+        if (i + 4 < 16) w0 = kfrag(i + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i < 8) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, qf[(i + 1) & 7], s0, 0, 0, 0);
+        else s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, qf[(i + 1) & 7], s1, 0, 0, 0);
+        if (i + 5 < 16) w1 = kfrag(i + 5);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i < 8) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, qf[(i + 2) & 7], s0, 0, 0, 0);
+        else s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, qf[(i + 2) & 7], s1, 0, 0, 0);
+        if (i + 6 < 16) w2 = kfrag(i + 6);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i < 8) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, qf[(i + 3) & 7], s0, 0, 0, 0);
+        else s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, qf[(i + 3) & 7], s1, 0, 0, 0);
+        if (i + 7 < 16) w3 = kfrag(i + 7);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    // lane holds kv_local = 32*half + 8*(r>>2) + 4*hi + (r&3) for its query column
+    if (valid < KVB) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kv = 8 * (r >> 2) + 4 * hi + (r & 3);
+        if (kv >= valid) s0[r] = -INFINITY;
+        if (kv + 32 >= valid) s1[r] = -INFINITY;
       }
     }
     float mx = s0[0];
@@ -154,40 +176,44 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs a) {
     }
     const float mc = m_run * c;
     float ls0 = 0.f, ls1 = 0.f;
+    bf16x8 pb[2][2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s0[r] = __builtin_amdgcn_exp2f(s0[r] * c - mc); ls0 += s0[r]; }
 #pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      union { uint32_t u[4]; bf16x8 v; } x0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x0.u[j] = pack2bf(s0[8 * cc + 2 * j], s0[8 * cc + 2 * j + 1]);
+      pb[0][cc] = x0.v;
+    }
+    // ---- O^T += V^T . P^T, kv half 0 (A operand element j of lane (d, hi) is V[32*half + 16*cc + 8*(j>>2) + 4*hi + (j&3)][d])
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const char* vp = vb + v_off + (16 * cc) * V_STRIDE + 64 * nb;
+        const bf16x8 vf = tr_pair(vp, vp + 8 * V_STRIDE);
+        o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[0][cc], o[nb], 0, 0, 0);
+      }
+#pragma unroll
     for (int r = 0; r < 16; ++r) { s1[r] = __builtin_amdgcn_exp2f(s1[r] * c - mc); ls1 += s1[r]; }
     l_run += ls0 + ls1;
-
-    // ---- P^T fragments: chunk (half, cc) = registers 8cc..8cc+7 packed to bf16
-    bf16x8 pb[2][2];
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
-      union { uint32_t u[4]; bf16x8 v; } x0, x1;
+      union { uint32_t u[4]; bf16x8 v; } x1;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        x0.u[j] = pack2bf(s0[8 * cc + 2 * j], s0[8 * cc + 2 * j + 1]);
-        x1.u[j] = pack2bf(s1[8 * cc + 2 * j], s1[8 * cc + 2 * j + 1]);
-      }
-      pb[0][cc] = x0.v;
+      for (int j = 0; j < 4; ++j) x1.u[j] = pack2bf(s1[8 * cc + 2 * j], s1[8 * cc + 2 * j + 1]);
       pb[1][cc] = x1.v;
     }
-
-    // ---- O^T += V^T . P^T : A operand element j of lane (d, hi) is V[32*half + 16*cc + 8*(j>>2) + 4*hi + (j&3)][d]
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
+    for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-          const char* vp = vb + v_off + (32 * hh + 16 * cc) * V_STRIDE + 64 * nb;
-          const bf16x8 vf = tr_pair(vp, vp + 8 * V_STRIDE);
-          o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[hh][cc], o[nb], 0, 0, 0);
-        }
+      for (int nb = 0; nb < 4; ++nb) {
+        const char* vp = vb + v_off + (32 + 16 * cc) * V_STRIDE + 64 * nb;
+        const bf16x8 vf = tr_pair(vp, vp + 8 * V_STRIDE);
+        o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[1][cc], o[nb], 0, 0, 0);
       }
-    }
     __builtin_amdgcn_s_setprio(0);
 
     if (t + 1 < total) stage_write(cur ^ 1);
@@ -211,6 +237,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs a) {
       }
   }
 }
+
 
 }  // namespace
 

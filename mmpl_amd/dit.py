@@ -133,3 +133,19 @@ class DitEngine:
             _lib.ptr(k_cache), _lib.ptr(v_cache), n_slots, _lib.ptr(cross_k), _lib.ptr(cross_v), _lib.ptr(out), _lib.ptr(ws),
             ws.numel(), _lib.stream_ptr()), "mmpl_dit_forward")
         return out
+
+    # ------------------------------------------------------------------ hipGraph
+    def capture(self, x: torch.Tensor, t: torch.Tensor, frame_ids, write_slots, visible_slots, k_cache, v_cache, cross_k, cross_v,
+                out: torch.Tensor) -> "torch.cuda.CUDAGraph":
+        """Capture one forward (fixed stage shape, slot table and buffers) into a hipGraph.  The forward is a pure launch
+        sequence -- no host sync, no allocation -- so replaying it costs one graph launch instead of ~13 launches per
+        layer.  `x`, `t`, `out` and the caches are captured BY ADDRESS: update their contents in place between replays
+        (that is what the denoise loop does: latents and the timestep change, the shapes never do)."""
+        self.workspace(x.shape[0])                      # allocate outside the capture
+        self.forward(x, t, frame_ids, write_slots, visible_slots, k_cache, v_cache, cross_k, cross_v, out=out)   # warm-up
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.forward(x, t, frame_ids, write_slots, visible_slots, k_cache, v_cache, cross_k, cross_v, out=out)
+        return g
+

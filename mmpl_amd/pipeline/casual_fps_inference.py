@@ -59,6 +59,7 @@ class CausalFPSInferencePipeline(torch.nn.Module):
         self.local_attn_size = -1
         self.handoff_sink: Optional[Callable[[torch.Tensor], None]] = None
         self.renoise_override = None      # tests: {frame: [1,16,h,w]} instead of torch.randn_like draws
+        self.use_graphs = True            # one hipGraph per (stage, cond|uncond) forward, replayed 50 + 1 times
 
         # ---- "add new noise on previous frames" schedule (casual_fps_inference.py:93-108); the randint keeps the
         # reference's RNG consumption order; the resulting timestep is >= 1000, i.e. pure noise
@@ -152,10 +153,22 @@ class CausalFPSInferencePipeline(torch.nn.Module):
                 flow_c = torch.empty_like(latents)
                 flow_u = torch.empty_like(latents)
                 timestep = torch.empty([1, len(frames)], device=dev, dtype=torch.float32)
+                graphs = None
+                if self.use_graphs:
+                    starts = [f * S for f in frames]
+                    timestep.fill_(float(sample_scheduler.timesteps[0]))
+                    graphs = (self.generator_cond.capture(latents, conditional_dict, timestep, self.kv_cache_pos,
+                                                          self.crossattn_cache_pos, starts, flow_c),
+                              self.generator_cond.capture(latents, unconditional_dict, timestep, self.kv_cache_neg,
+                                                          self.crossattn_cache_neg, starts, flow_u))
                 for t in sample_scheduler.timesteps:
                     timestep.fill_(float(t))
-                    self._forward(latents, conditional_dict, timestep, self.kv_cache_pos, self.crossattn_cache_pos, frames, flow_c)
-                    self._forward(latents, unconditional_dict, timestep, self.kv_cache_neg, self.crossattn_cache_neg, frames, flow_u)
+                    if graphs is not None:
+                        graphs[0].replay()
+                        graphs[1].replay()
+                    else:
+                        self._forward(latents, conditional_dict, timestep, self.kv_cache_pos, self.crossattn_cache_pos, frames, flow_c)
+                        self._forward(latents, unconditional_dict, timestep, self.kv_cache_neg, self.crossattn_cache_neg, frames, flow_u)
                     # flow = uncond + g (cond - uncond); latents = scheduler.step(flow)  -- one fused kernel (:366-374)
                     sample_scheduler.step_cfg(flow_c, flow_u, self.args.guidance_scale, latents)
 
@@ -167,7 +180,12 @@ class CausalFPSInferencePipeline(torch.nn.Module):
                         self.handoff_sink(save_latents)
                     elif self.save:
                         torch.save(save_latents, self.save)
-                self._refresh(latents, conditional_dict, unconditional_dict, timestep, frames)
+                if graphs is not None:                                          # refresh pass = same graphs at t = 0
+                    timestep.zero_()
+                    graphs[0].replay()
+                    graphs[1].replay()
+                else:
+                    self._refresh(latents, conditional_dict, unconditional_dict, timestep, frames)
 
             video = None
             if decode:

@@ -136,6 +136,26 @@ class WanFPSWrapper(torch.nn.Module):
     def new_crossattn_cache(self) -> CrossAttnCache:
         return CrossAttnCache(self.engine)
 
+    def capture(self, noisy_image_or_video, conditional_dict, timestep, kv_cache, crossattn_cache, current_start, out):
+        """hipGraph of this exact forward (fixed buffers / stage shape); returns the graph, replay() re-runs it on the
+        current contents of `noisy_image_or_video`, `timestep` and the caches."""
+        assert noisy_image_or_video.is_contiguous() and noisy_image_or_video.dtype == torch.bfloat16
+        assert timestep.dtype == torch.float32 and timestep.is_contiguous() and out.is_contiguous()
+        S = self.engine.S
+        if not crossattn_cache.is_init:
+            pe = conditional_dict["prompt_embeds"]
+            crossattn_cache.fill(pe[0] if pe.dim() == 3 else pe)
+        starts = [int(s) for s in current_start]
+        frames = [s // S for s in starts]
+        vis = kv_cache.vis
+        if 15 * S not in starts:
+            for s in starts:
+                if s not in vis:
+                    vis.append(s)
+        return self.engine.capture(noisy_image_or_video[0], timestep.view(-1), frames, StagePlan.write_slots(frames),
+                                   [slot_of(o // S) for o in vis], kv_cache.k_all, kv_cache.v_all, crossattn_cache.k_all,
+                                   crossattn_cache.v_all, out[0])
+
     def forward(self, noisy_image_or_video: torch.Tensor, conditional_dict: dict, timestep: torch.Tensor,
                 kv_cache: Optional[KVCache] = None, crossattn_cache: Optional[CrossAttnCache] = None,
                 current_start=None, classify_mode=False, concat_time_embeddings=False, clean_x=None, aug_t=None,

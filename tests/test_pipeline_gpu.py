@@ -61,6 +61,11 @@ def test_t2v_first_chunk_latents_and_handoff():
     print(f"t2v chunk 1: rel_l2 latents = {e:.3e}, hand-off = {eh:.3e}")
     assert got["h"].shape == (1, 8, 16, *LAT)
     assert e < 4e-2 and eh < 4e-2
+    # hipGraph replay (default) and eager launches give bit-identical chunks
+    pipe.use_graphs = False
+    _, lat_eager = pipe.inference(noise.cuda(), ["a cat"], return_latents=True, decode=False)
+    assert torch.equal(lat_eager, lat)
+    pipe.use_graphs = True
     # second call on the same pipeline re-uses (and resets) the caches: chunk >= 2 with an initial latent
     init = philox_normal([1, 2, 16, *LAT], 55)
     _, lat2 = pipe.inference(noise.cuda(), ["a cat"], initial_latent=init.cuda(), return_latents=True, decode=False)
