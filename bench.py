@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--res", default="720p", choices=["480p", "720p", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="disable the per-kernel hipEvent pairs")
+    ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-region) VAE decode measurement")
     return ap.parse_args()
 
 
@@ -179,6 +180,26 @@ def main():
         lib.mmpl_profile_read(n, ms, fl, cnt)
         lib.mmpl_profile_enable(0)
         prof = {KIND_NAMES[k]: dict(ms=ms[k], flops=fl[k], launches=int(cnt[k])) for k in range(n) if cnt[k]}
+    vae_s = None
+    if rank == 0 and not args.no_vae:
+        # Wan 3D-VAE decode of one 21-latent-frame chunk (reported separately from the DiT metric)
+        try:
+            from mmpl_amd.synthetic import vae_state_dict
+            from mmpl_amd.vae import VaeEngine
+            from mmpl_amd.wan_wrapper import WanVAEWrapper
+            for st in stage_state:
+                st.clear()
+            ve = VaeEngine(lat_h, lat_w, dev)
+            ve.load_state_dict(vae_state_dict(seed=7))
+            z = torch.randn(21, 16, lat_h, lat_w, device=dev).to(torch.bfloat16)
+            ve.decode(z[:2], WanVAEWrapper.mean, WanVAEWrapper.std)
+            torch.cuda.synchronize()
+            tv = time.perf_counter()
+            ve.decode(z, WanVAEWrapper.mean, WanVAEWrapper.std)
+            torch.cuda.synchronize()
+            vae_s = time.perf_counter() - tv
+        except Exception as e:
+            vae_s = f"failed: {e!r}"
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -204,6 +225,7 @@ def main():
             "sec_per_chunk_extrapolated": chunk_s,
             "achieved_pflops_per_gpu": achieved_pf,
             "mfma_frac_whole_step": achieved_pf * 1e3 / MFMA_PEAK_TFLOPS,
+            "vae_decode_s_per_chunk": vae_s,
         }
         if prof and "attn_self" in prof:
             a = prof["attn_self"]

@@ -110,3 +110,15 @@ def test_decode_and_handoff_transform():
     e = rel_l2(init, ref_init)
     print(f"hand-off transform: rel_l2 = {e:.3e}")
     assert init.shape == (1, 2, 16, *LAT) and e < 4e-2
+
+
+def test_cli_two_chunk_rollout_synthetic(tmp_path):
+    """The entry point (reference CLI) end to end on one GPU: 2 chunks, tiny model, 16x24 latents, 2 sampling steps:
+    rolling hand-over through the VAE, 5-frame overlap dropped when stitching (Wan_fps_inference_1gpu.py:164-203)."""
+    from mmpl_amd import cli
+    out = tmp_path / "out"
+    cli.main(["--synthetic", "--model", "tiny", "--latent_hw", "16", "24", "--duration", "2", "--sampling_steps", "2",
+              "--output_folder", str(out)])
+    v = torch.load(out / "0-0.pt")
+    assert v.shape == (81 + 76, 128, 192, 3) and v.dtype == torch.uint8
+    assert v.float().std() > 1.0
