@@ -352,6 +352,7 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
       AttnArgs a = {};
       a.q = w.big; a.ldq = d; a.o = w.attn; a.ldo = d; a.ldk = d; a.ldv = d; a.page_rows = T; a.Lq = Lq; a.H = H; a.scale = scale;
       a.n_pages = 1;
+      a.cross = 1;
       a.k_pages[0] = (const bf16_t*)cross_k + (size_t)l * T * d;
       a.v_pages[0] = (const bf16_t*)cross_v + (size_t)l * T * d;
       ProfScope ps(K_ATTN_CROSS, 4.0 * Lq * (double)T * d, s);

@@ -35,6 +35,9 @@ MMPL_DEV bf16x8 tr_pair(const char* p0, const char* p1) {
   return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
+// CROSS only tags the symbol (attn_fwd_kernel<0> = self-attention over cache pages, <1> = text cross-attention) so that
+// profiles report the two launch populations separately; the code is identical.
+template <int CROSS>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -248,12 +251,15 @@ hipError_t mmpl_launch_attention(const AttnArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const int n_qb = (a.Lq + QB - 1) / QB;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(n_qb * a.H), dim3(512), SMEM, s, a);
+  if (a.cross) hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(n_qb * a.H), dim3(512), SMEM, s, a);
+  else hipLaunchKernelGGL(attn_fwd_kernel<0>, dim3(n_qb * a.H), dim3(512), SMEM, s, a);
   return hipGetLastError();
 }

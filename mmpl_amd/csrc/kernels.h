@@ -32,6 +32,7 @@ struct AttnArgs {
   int n_pages, page_rows;
   int Lq, H;
   float scale;                     // softmax scale (1/sqrt(128))
+  int cross;                       // 1: text cross-attention launch (symbol tag only)
 };
 hipError_t mmpl_launch_attention(const AttnArgs& a, hipStream_t s);
 
