@@ -49,6 +49,8 @@ def main(argv=None):
     ap.add_argument("--output_folder", type=str, default="outputs")
     ap.add_argument("--num_output_frames", type=int, default=21)
     ap.add_argument("--use_ema", action="store_true")
+    ap.add_argument("--i2v", action="store_true", help="image-to-video: the VAE-encoded image is latent frame 0 (MMPL_i2v)")
+    ap.add_argument("--image", type=str, help="input image for --i2v (any PIL-readable file)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--duration", type=int, default=3, help="number of 21-latent-frame chunks")
     ap.add_argument("--resolution", default="480p", choices=["480p", "720p"])
@@ -81,7 +83,19 @@ def main(argv=None):
         vae = WanVAEWrapper(geometry=geo, device=dev, state_dict=vae_state_dict(seed=2))
     else:
         enc, vae = None, None       # reference checkpoints under ../wan_models (wan_wrapper.local_wan_path)
-    pipe = CausalFPSInferencePipeline(config, dev, generator=gen, text_encoder=enc, vae=vae, device_cond=dev, device_uncond=dev, save=None)
+    mode = "i2v" if args.i2v else "t2v"
+    pipe = CausalFPSInferencePipeline(config, dev, generator=gen, text_encoder=enc, vae=vae, device_cond=dev, device_uncond=dev, save=None,
+                                      mode=mode, geometry=geo)
+    image_latent = None
+    if args.i2v:
+        # I2V/Wan_fps_inference_1gpu.py:74-79,100-104: Resize -> ToTensor -> Normalize(0.5, 0.5) -> vae.encode_to_latent
+        import numpy as np
+        from PIL import Image
+        H, W = geo.pixel_hw
+        img = Image.open(args.image).convert("RGB").resize((W, H), Image.BILINEAR)
+        px = torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1).float() / 255.0
+        px = ((px - 0.5) / 0.5).unsqueeze(0).unsqueeze(2).to(device=dev, dtype=torch.bfloat16)      # [1, 3, 1, H, W]
+        image_latent = pipe.vae.encode_to_latent(px).to(torch.bfloat16)                                # [1, 1, 16, h, w]
     if args.checkpoint_path:
         sd = torch.load(args.checkpoint_path, map_location="cpu")
         pipe.generator_cond.load_state_dict(sd["generator" if not args.use_ema else "generator_ema"])
@@ -95,16 +109,18 @@ def main(argv=None):
         g = torch.Generator(device="cpu").manual_seed(args.seed)
         noises = [torch.randn(shape, generator=g).to(torch.bfloat16) for _ in range(args.duration)]
         if world == 1:
-            videos, initial = [], None
+            videos, initial = [], image_latent
             for c in range(args.duration):
                 video, _ = pipe.inference(noises[c].to(dev), [prompt], initial_latent=initial, return_latents=True)
                 initial = rolling_initial_latent(pipe.vae, video)
                 videos.append(video.cpu())
         else:
-            ho = ChunkHandoff((1, 8, 16, geo.lat_h, geo.lat_w), dev)
+            ho = ChunkHandoff((1, 3 if args.i2v else 8, 16, geo.lat_h, geo.lat_w), dev)
 
             def make_chunk(c, initial, sink):
                 pipe.handoff_sink = sink
+                if c == 0:
+                    initial = image_latent
                 video, _ = pipe.inference(noises[c].to(dev), [prompt], initial_latent=initial, return_latents=True)
                 return video
 

@@ -122,3 +122,18 @@ def test_cli_two_chunk_rollout_synthetic(tmp_path):
     v = torch.load(out / "0-0.pt")
     assert v.shape == (81 + 76, 128, 192, 3) and v.dtype == torch.uint8
     assert v.float().std() > 1.0
+
+
+def test_cli_i2v_synthetic(tmp_path):
+    """--i2v: image -> VAE encode -> latent frame 0 -> I2V stage plan (MMPL_i2v entry path), one chunk."""
+    import numpy as np
+    from PIL import Image
+    from mmpl_amd import cli
+    rng = np.random.default_rng(0)
+    img = tmp_path / "in.png"
+    Image.fromarray(rng.integers(0, 255, (90, 130, 3), dtype=np.uint8)).save(img)
+    out = tmp_path / "out"
+    cli.main(["--synthetic", "--model", "tiny", "--latent_hw", "16", "24", "--duration", "1", "--sampling_steps", "1", "--i2v",
+              "--image", str(img), "--output_folder", str(out)])
+    v = torch.load(out / "0-0.pt")
+    assert v.shape == (81, 128, 192, 3)
