@@ -28,7 +28,8 @@ MMPL_DEV float gelu_tanh(float x) {
   // torch GELU(approximate='tanh'): 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3)))
   const float kBeta = 0.7978845608028654f, kKappa = 0.044715f;
   float inner = kBeta * (x + kKappa * x * x * x);
-  return 0.5f * x * (1.0f + tanhf(inner));
+  // 0.5 * (1 + tanh(u)) == 1 / (1 + exp(-2u))
+  return x / (1.0f + __expf(-2.0f * inner));
 }
 MMPL_DEV float silu(float x) { return x / (1.0f + __expf(-x)); }
 

@@ -18,6 +18,7 @@ struct GemmArgs {
   int gate_frame_stride;
   int rows_per_frame;
   float alpha;                   // EPI_F32_SCALE: C is float*, C = alpha * acc (no bias)
+  int group;                     // M-tile group size of the block order (set by the launcher)
 };
 hipError_t mmpl_launch_gemm(const GemmArgs& g, hipStream_t s);
 

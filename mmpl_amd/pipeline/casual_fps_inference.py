@@ -180,7 +180,11 @@ class CausalFPSInferencePipeline(torch.nn.Module):
                         self.handoff_sink(save_latents)
                     elif self.save:
                         torch.save(save_latents, self.save)
-                if graphs is not None:                                          # refresh pass = same graphs at t = 0
+                # the stage that does not persist its K/V ([13..18]) gains nothing from the refresh pass: the reference
+                # runs it anyway (casual_fps_inference.py:385-403) but it writes no cache and its output is dropped
+                if self.plan.write_slots(frames)[0] < 0:
+                    pass
+                elif graphs is not None:                                        # refresh pass = same graphs at t = 0
                     timestep.zero_()
                     graphs[0].replay()
                     graphs[1].replay()
