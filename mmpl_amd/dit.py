@@ -142,7 +142,9 @@ class DitEngine:
         layer.  `x`, `t`, `out` and the caches are captured BY ADDRESS: update their contents in place between replays
         (that is what the denoise loop does: latents and the timestep change, the shapes never do)."""
         self.workspace(x.shape[0])                      # allocate outside the capture
-        self.forward(x, t, frame_ids, write_slots, visible_slots, k_cache, v_cache, cross_k, cross_v, out=out)   # warm-up
+        if not getattr(self, "_warm", False):           # one eager call per engine: lazy kernel attributes are set outside
+            self.forward(x, t, frame_ids, write_slots, visible_slots, k_cache, v_cache, cross_k, cross_v, out=out)
+            self._warm = True
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
