@@ -115,6 +115,25 @@ int mmpl_vae_decode(MmplVae* v, const void* z, int n_frames, const float* mean, 
 int mmpl_vae_encode(MmplVae* v, const void* px, int n_px_frames, const float* mean, const float* inv_std, void* out, void* workspace,
                     size_t workspace_bytes, mmpl_stream_t stream);
 
+/* ---- umT5 text encoder (wan/modules/t5.py:267-312 behind WanTextEncoder, utils/wan_wrapper.py:15-51) ----
+ * Weights (bf16 dev pointers): [token_embedding.weight, norm.weight] then per block
+ * [norm1.weight, pack:attn.{q,k,v}.weight[3*dim_attn,dim], attn.o.weight, pos_embedding.embedding.weight[num_buckets,heads],
+ *  norm2.weight, ffn.gate.0.weight, ffn.fc1.weight, ffn.fc2.weight].
+ * mmpl_t5_encode: ids / mask dev int32 [text_len]; bucket dev int32 [2*text_len-1] = relative-position bucket of (j - i)
+ * at index j - i + text_len - 1 (t5.py:240-264, computed host-side); out dev bf16 [text_len, dim], padding rows zeroed. */
+typedef struct MmplT5Config {
+  int vocab, dim, dim_attn, dim_ffn, num_heads, num_layers, num_buckets, text_len;
+  float eps;
+} MmplT5Config;
+typedef struct MmplT5 MmplT5;
+int mmpl_t5_num_weights(const MmplT5Config* cfg);
+int mmpl_t5_create(const MmplT5Config* cfg, MmplT5** out);
+void mmpl_t5_destroy(MmplT5* h);
+int mmpl_t5_bind_weights(MmplT5* h, const void* const* dev_ptrs, int n);
+size_t mmpl_t5_workspace_bytes(const MmplT5* h);
+int mmpl_t5_encode(MmplT5* h, const int* ids, const int* mask, const int* bucket, void* out, void* workspace,
+                   size_t workspace_bytes, mmpl_stream_t stream);
+
 /* Optional per-kernel-class hipEvent timing (bench.py's live roofline numbers; off by default, not thread-safe).
  * kinds: 0 gemm, 1 self-attention, 2 cross-attention, 3 layernorm, 4 qk-norm/rope/kv-write, 5 elementwise, 6 cfg+unipc,
  * 7 vae.  mmpl_profile_read synchronises the device, sums the event pairs recorded since enable/last read. */

@@ -14,6 +14,7 @@ SYMBOLS = [
     "mmpl_attn_fwd", "mmpl_gemm", "mmpl_layernorm", "mmpl_qknorm_rope", "mmpl_cfg_unipc_step",
     "mmpl_vae_num_weights", "mmpl_vae_weight_name", "mmpl_vae_create", "mmpl_vae_destroy", "mmpl_vae_bind_weights",
     "mmpl_vae_workspace_bytes", "mmpl_vae_decode", "mmpl_vae_encode",
+    "mmpl_t5_num_weights", "mmpl_t5_create", "mmpl_t5_destroy", "mmpl_t5_bind_weights", "mmpl_t5_workspace_bytes", "mmpl_t5_encode",
     "mmpl_profile_enable", "mmpl_profile_read", "mmpl_last_error", "mmpl_version",
 ]
 
@@ -22,6 +23,11 @@ class MmplDitConfig(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("dim", "ffn_dim", "num_heads", "num_layers", "text_dim", "freq_dim", "in_dim",
                                        "out_dim", "text_len")] + [("eps", C.c_float)] + \
                [(n, C.c_int) for n in ("lat_h", "lat_w", "max_frames")]
+
+
+class MmplT5Config(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("vocab", "dim", "dim_attn", "dim_ffn", "num_heads", "num_layers", "num_buckets", "text_len")] + \
+               [("eps", C.c_float)]
 
 
 class MmplUniPCStep(C.Structure):
@@ -68,6 +74,14 @@ def load() -> C.CDLL:
     lib.mmpl_cfg_unipc_step.argtypes = [vp, vp, vp, vp, vp, vp, sz, C.POINTER(MmplUniPCStep), vp]
     lib.mmpl_profile_enable.argtypes = [ci]
     lib.mmpl_profile_read.argtypes = [ci, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+    lib.mmpl_t5_num_weights.argtypes = [C.POINTER(MmplT5Config)]
+    lib.mmpl_t5_create.argtypes = [C.POINTER(MmplT5Config), C.POINTER(vp)]
+    lib.mmpl_t5_destroy.argtypes = [vp]
+    lib.mmpl_t5_destroy.restype = None
+    lib.mmpl_t5_bind_weights.argtypes = [vp, C.POINTER(vp), ci]
+    lib.mmpl_t5_workspace_bytes.argtypes = [vp]
+    lib.mmpl_t5_workspace_bytes.restype = sz
+    lib.mmpl_t5_encode.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp]
     if hasattr(lib, "mmpl_vae_create"):
         _bind_vae(lib)
     _lib = lib

@@ -218,7 +218,7 @@ FwdWs carve_fwd(const MmplDit* h, int nF, void* base) {
 
 int gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, bf16_t* C, int ldc, int M, int N, int K,
          int epi, const bf16_t* res, int ldres, const bf16_t* gate, int gfs, int rpf, hipStream_t s) {
-  GemmArgs g{A, lda, W, ldw, bias, C, ldc, M, N, K, epi, res, ldres, gate, gfs, rpf > 0 ? rpf : 1, 1.0f};
+  GemmArgs g{A, lda, W, ldw, bias, C, ldc, M, N, K, epi, res, ldres, gate, gfs, rpf > 0 ? rpf : 1, 1.0f, 0, 0, 0, 0, 0};
   ProfScope ps(K_GEMM, 2.0 * M * (double)N * K, s);
   hipError_t e = mmpl_launch_gemm(g, s);
   if (e != hipSuccess) return fail("gemm", hipGetErrorString(e));

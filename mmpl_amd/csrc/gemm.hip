@@ -79,6 +79,11 @@ MMPL_DEV void gemm_epilogue(const GemmArgs& g, const f32x4 (&acc)[4][4], int mw,
 
 template <int EPI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel(GemmArgs g) {
+  if (g.batch > 1) {
+    g.A += (size_t)blockIdx.y * g.sA;
+    g.W += (size_t)blockIdx.y * g.sW;
+    g.C = (bf16_t*)((char*)g.C + (size_t)blockIdx.y * g.sC * (g.epi == EPI_F32_SCALE ? 4 : 2));
+  }
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* As = smem;                   // [2][128][64] bf16, swizzled
   char* Ws = smem + 2 * TILE_BYTES;  // [2][128][64]
@@ -529,10 +534,10 @@ hipError_t launch_v3(const GemmArgs& g, hipStream_t s) {
 
 template <int EPI>
 hipError_t launch(const GemmArgs& g, hipStream_t s) {
-  const bool big = g.M >= 1024 && g.N >= 256 && g.K >= 128 && !getenv("MMPL_GEMM_V1") && !getenv("MMPL_GEMM_V2");
+  const bool big = g.batch <= 1 && g.M >= 1024 && g.N >= 256 && g.K >= 128 && !getenv("MMPL_GEMM_V1") && !getenv("MMPL_GEMM_V2");
   if (big && getenv("MMPL_GEMM_V3")) return launch_v3<EPI>(g, s);
   if (big) return launch_v4<EPI>(g, s);
-  if (g.M >= 1024 && g.N >= 128 && g.K >= 128 && !getenv("MMPL_GEMM_V1")) return launch_v2<EPI>(g, s);
+  if (g.batch <= 1 && g.M >= 1024 && g.N >= 128 && g.K >= 128 && !getenv("MMPL_GEMM_V1")) return launch_v2<EPI>(g, s);
   static bool attr_set = false;
   constexpr int smem = 4 * TILE_BYTES;
   if (!attr_set) {
@@ -542,7 +547,7 @@ hipError_t launch(const GemmArgs& g, hipStream_t s) {
     attr_set = true;
   }
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-  hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(tiles), dim3(256), smem, s, g);
+  hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(tiles, g.batch > 1 ? g.batch : 1), dim3(256), smem, s, g);
   return hipGetLastError();
 }
 

@@ -19,6 +19,8 @@ struct GemmArgs {
   int rows_per_frame;
   float alpha;                   // EPI_F32_SCALE: C is float*, C = alpha * acc (no bias)
   int group;                     // M-tile group size of the block order (set by the launcher)
+  int batch;                     // > 1: batched (blockIdx.y); element strides below; small-problem kernel only
+  long sA, sW, sC;
 };
 hipError_t mmpl_launch_gemm(const GemmArgs& g, hipStream_t s);
 

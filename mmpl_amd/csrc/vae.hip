@@ -135,7 +135,7 @@ void conv(Ctx& c, const bf16_t* src, int Cin, int Hp, int Wp, int st, int sy, in
 void gemm(Ctx& c, const bf16_t* A, int lda, const bf16_t* Wt, int ldw, const bf16_t* bias, void* C, int ldc, int M, int N, int K, int epi,
           const bf16_t* res, int ldres, float alpha = 1.f) {
   if (c.dry) return;
-  GemmArgs g{A, lda, Wt, ldw, bias, (bf16_t*)C, ldc, M, N, K, epi, res, ldres, nullptr, 0, 1, alpha};
+  GemmArgs g{A, lda, Wt, ldw, bias, (bf16_t*)C, ldc, M, N, K, epi, res, ldres, nullptr, 0, 1, alpha, 0, 0, 0, 0, 0};
   c.chk(mmpl_launch_gemm(g, c.s), "gemm");
 }
 

@@ -168,3 +168,38 @@ def vae_state_dict(seed: int = 0, dtype=torch.bfloat16, device="cpu") -> "Ordere
             t = torch.randn(*shape, generator=g, device=device) * (1.0 / math.sqrt(fan_in))
         sd[name] = t.to(dtype)
     return sd
+
+
+# ---------------------------------------------------------------------------------------------- umT5 encoder weights
+T5_CONFIGS = {
+    "umt5-xxl": dict(vocab=256384, dim=4096, dim_attn=4096, dim_ffn=10240, num_heads=64, num_layers=24, num_buckets=32),
+    "tiny": dict(vocab=1000, dim=256, dim_attn=256, dim_ffn=512, num_heads=4, num_layers=2, num_buckets=32),
+    "small": dict(vocab=4000, dim=512, dim_attn=512, dim_ffn=1280, num_heads=8, num_layers=3, num_buckets=32),
+}
+
+
+def t5_state_dict(cfg: dict, seed: int = 0, dtype=torch.bfloat16, device="cpu") -> "OrderedDict[str, torch.Tensor]":
+    """Keys / shapes of `T5Encoder.state_dict()` (MMPL_t2v/wan/modules/t5.py:267-312, shared_pos=False); init as t5.py:27-42."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    d, da, df, n, nb = cfg["dim"], cfg["dim_attn"], cfg["dim_ffn"], cfg["num_heads"], cfg["num_buckets"]
+
+    def rn(*shape, std):
+        return (torch.randn(*shape, generator=g, device=device) * std).to(dtype)
+
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    sd["token_embedding.weight"] = rn(cfg["vocab"], d, std=1.0)
+    for i in range(cfg["num_layers"]):
+        p = f"blocks.{i}."
+        sd[p + "norm1.weight"] = (1 + 0.1 * torch.randn(d, generator=g, device=device)).to(dtype)
+        sd[p + "attn.q.weight"] = rn(da, d, std=(d * (da // n)) ** -0.5 * 4)
+        sd[p + "attn.k.weight"] = rn(da, d, std=d ** -0.5)
+        sd[p + "attn.v.weight"] = rn(da, d, std=d ** -0.5)
+        sd[p + "attn.o.weight"] = rn(d, da, std=da ** -0.5)
+        sd[p + "norm2.weight"] = (1 + 0.1 * torch.randn(d, generator=g, device=device)).to(dtype)
+        sd[p + "ffn.gate.0.weight"] = rn(df, d, std=d ** -0.5)
+        sd[p + "ffn.fc1.weight"] = rn(df, d, std=d ** -0.5)
+        sd[p + "ffn.fc2.weight"] = rn(d, df, std=df ** -0.5)
+        sd[p + "pos_embedding.embedding.weight"] = rn(nb, n, std=0.5)
+    sd["norm.weight"] = (1 + 0.1 * torch.randn(d, generator=g, device=device)).to(dtype)
+    return sd

@@ -191,27 +191,76 @@ class WanFPSWrapper(torch.nn.Module):
 
 
 class WanTextEncoder(torch.nn.Module):
-    """Seam for the umT5-xxl encoder (utils/wan_wrapper.py:15-51).  Pass `encode_fn(prompts) -> [B, 512, 4096]`; the
-    padding rows must already be zero (wan_wrapper.py:46-47)."""
+    """utils/wan_wrapper.py:15-51 on the HIP umT5 engine (mmpl_amd/t5.py): tokenizer (seq_len 512, whitespace clean,
+    tokenizers.py:38-82) -> encoder -> padding rows zeroed.  The engine computes in bf16 (the reference's generate.py
+    T5 dtype, wan/configs/shared_config.py; its fps wrapper upcasts the same bf16 checkpoint to fp32 on the CPU -- the
+    difference is the bf16 rounding the DiT's text_embedding applies to the context anyway; tests/test_t5_gpu.py).
 
-    def __init__(self, encode_fn=None):
+    ``encode_fn(prompts) -> [B, 512, 4096]`` overrides everything (precomputed embeddings); otherwise pass
+    ``state_dict`` or let it load ``models_t5_umt5-xxl-enc-bf16.pth`` from ``local_wan_path``."""
+
+    def __init__(self, encode_fn=None, state_dict: Optional[dict] = None, pretrained_path: Optional[str] = None,
+                 tokenizer=None, tokenizer_path: Optional[str] = None, cfg: Optional[dict] = None, text_len: int = 512,
+                 device="cuda:0"):
         super().__init__()
         self.encode_fn = encode_fn
+        self.text_len = text_len
+        self.tokenizer = tokenizer
+        self.tokenizer_path = tokenizer_path or f"{local_wan_path}/Wan2.1-T2V-14B/google/umt5-xxl/"
+        self.model = None
+        if encode_fn is not None:
+            return
+        path = pretrained_path or f"{local_wan_path}/Wan2.1-T2V-14B/models_t5_umt5-xxl-enc-bf16.pth"
+        if state_dict is None and os.path.exists(path):
+            state_dict = torch.load(path, map_location="cpu", weights_only=False)
+        if state_dict is not None:
+            from .synthetic import T5_CONFIGS
+            from .t5 import T5Engine
+            self.model = T5Engine(cfg or T5_CONFIGS["umt5-xxl"], text_len=text_len, device=device)
+            self.model.load_state_dict(state_dict)
+
+    def to(self, *args, **kwargs):
+        return self
+
+    @staticmethod
+    def _clean(text: str) -> str:
+        """clean='whitespace' (tokenizers.py:12-21); ftfy.fix_text is applied when ftfy is installed."""
+        import html
+        import re
+        try:
+            import ftfy
+            text = ftfy.fix_text(text)
+        except ImportError:
+            pass
+        text = html.unescape(html.unescape(text)).strip()
+        return re.sub(r"\s+", " ", text).strip()
+
+    def tokenize(self, text_prompts: List[str]):
+        if self.tokenizer is None:
+            from transformers import AutoTokenizer
+            self.tokenizer = AutoTokenizer.from_pretrained(self.tokenizer_path)
+        enc = self.tokenizer([self._clean(p) for p in text_prompts], return_tensors="pt", padding="max_length", truncation=True,
+                             max_length=self.text_len, add_special_tokens=True)
+        return enc.input_ids, enc.attention_mask
 
     def forward(self, text_prompts: List[str]) -> dict:
-        if self.encode_fn is None:
-            raise NotImplementedError("umT5-xxl is not part of this round's hot path; pass encode_fn or precomputed embeddings")
-        return {"prompt_embeds": self.encode_fn(text_prompts)}
+        if self.encode_fn is not None:
+            return {"prompt_embeds": self.encode_fn(text_prompts)}
+        if self.model is None:
+            raise RuntimeError("WanTextEncoder: no umT5 weights (models_t5_umt5-xxl-enc-bf16.pth not found and no state_dict / "
+                               "encode_fn given)")
+        ids, mask = self.tokenize(text_prompts)
+        return {"prompt_embeds": self.model.encode(ids, mask)}      # padding rows zeroed inside mmpl_t5_encode
 
 
 class SyntheticTextEncoder(WanTextEncoder):
     """Deterministic stand-in used by tests / bench: a prompt hashes to a seed for N(0,1) embeddings, pad rows zeroed."""
 
     def __init__(self, text_dim=4096, device="cuda:0", n_valid=64):
-        super().__init__(None)
+        super().__init__(encode_fn=self._encode)
         self.text_dim, self.dev, self.n_valid = text_dim, device, n_valid
 
-    def forward(self, text_prompts: List[str]) -> dict:
+    def _encode(self, text_prompts: List[str]) -> torch.Tensor:
         import zlib
         from .synthetic import philox_normal
         outs = []
@@ -219,7 +268,7 @@ class SyntheticTextEncoder(WanTextEncoder):
             e = philox_normal([512, self.text_dim], zlib.crc32(p.encode("utf-8")))
             e[self.n_valid:] = 0
             outs.append(e)
-        return {"prompt_embeds": torch.stack(outs).to(self.dev)}
+        return torch.stack(outs).to(self.dev)
 
 
 class WanVAEWrapper(torch.nn.Module):
