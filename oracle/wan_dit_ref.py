@@ -229,7 +229,7 @@ def dit_forward(p: Dict[str, torch.Tensor], cfg: DitCfg, x: torch.Tensor, t: tor
     """
     nF, gh, gw = x.shape[1], x.shape[2] // 2, x.shape[3] // 2
     S = gh * gw
-    freqs = rope_table(cfg.head_dim)
+    freqs = rope_table(cfg.head_dim).to(x.device)
     h = F.conv3d(x.unsqueeze(0), p["patch_embedding.weight"], p["patch_embedding.bias"], stride=(1, 2, 2))
     h = h.flatten(2).transpose(1, 2)                                   # [1, nF*S, dim]
     e, e0 = time_embed(p, cfg, t, h)
