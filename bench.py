@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="disable the per-kernel hipEvent pairs")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-region) VAE decode measurement")
+    ap.add_argument("--cfg-split", action="store_true",
+                    help="N/2 chunk lanes x (cond, uncond) rank pairs exchanging flow predictions every step "
+                         "(the reference's device_cond/device_uncond seam) instead of N chunk lanes")
     return ap.parse_args()
 
 
@@ -89,6 +92,12 @@ def main():
     assert args.steps % 4 == 0 and args.steps > 0, "--steps must be a positive multiple of 4 (one per T2V stage shape)"
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
+    pair, lanes, lane, n_lanes = None, None, rank, world
+    if args.cfg_split:
+        assert world >= 2 and world % 2 == 0, "--cfg-split needs an even number of ranks"
+        from mmpl_amd.handoff import CfgPair
+        pair, _, lay = CfgPair.build(world, dev, cfg_split=True)
+        lanes, lane, n_lanes = lay["heads"], lay["lane_of"][rank], world // 2
 
     from mmpl_amd import _lib
     from mmpl_amd.dit import DitEngine
@@ -107,7 +116,7 @@ def main():
 
     # two KV caches (cond / uncond) filled with unit-variance data so softmax sees realistic score spreads
     caches = []
-    for i in range(2):
+    for i in range(2 if pair is None else 1):                 # a CFG pair rank owns one branch only
         kc, vc = eng.new_kv_cache(N_SLOTS)
         kc.normal_()
         vc.normal_()
@@ -123,8 +132,11 @@ def main():
         sched = FlowUniPCMultistepScheduler(1000, 2, 1.0)
         sched.set_timesteps(50, shift=5.0)
         vis = [slot_of(f) for f in vis_frames[si]]
+        if pair is not None:
+            pair.broadcast(lat)
+        flow = torch.empty((2,) + tuple(lat.shape), device=dev, dtype=lat.dtype)
         stage_state.append(dict(frames=frames, lat=lat, sched=sched, vis=vis, ws=plan.write_slots(frames),
-                                fc=torch.empty_like(lat), fu=torch.empty_like(lat),
+                                fc=flow[0], fu=flow[1], flow=flow, mine=torch.empty_like(lat),
                                 t=torch.empty(len(frames), dtype=torch.float32, device=dev)))
     handoff_send = torch.zeros(8, 16, lat_h, lat_w, device=dev, dtype=torch.bfloat16)
     handoff_recv = torch.zeros_like(handoff_send)
@@ -136,11 +148,16 @@ def main():
         if sched.step_index >= 50:
             sched.set_timesteps(50, shift=5.0)
         st["t"].fill_(float(sched.timesteps[sched.step_index]))
-        for which, out in ((0, st["fc"]), (1, st["fu"])):
-            kc, vc, ck, cv = caches[which]
-            eng.forward(st["lat"], st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out)
+        if pair is None:
+            for which, out in ((0, st["fc"]), (1, st["fu"])):
+                kc, vc, ck, cv = caches[which]
+                eng.forward(st["lat"], st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out)
+        else:
+            kc, vc, ck, cv = caches[0]
+            eng.forward(st["lat"], st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=st["mine"])
+            pair.exchange(st["mine"], st["flow"])
         sched.step_cfg(st["fc"], st["fu"], 5.0, st["lat"])
-        if dist is not None and i % 4 == 1:
+        if dist is not None and i % 4 == 1 and (pair is None or pair.role == 0):
             # chunk hand-off of the anchor stage (casual_fps_inference.py:380-383 -> RCCL p2p on a side stream,
             # overlapped with the next stage's compute): rank r -> r+1
             handoff_send[0].copy_(st["lat"][0])
@@ -148,10 +165,12 @@ def main():
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 ops = []
-                if rank + 1 < world:
-                    ops.append(dist.P2POp(dist.isend, handoff_send, rank + 1))
-                if rank > 0:
-                    ops.append(dist.P2POp(dist.irecv, handoff_recv, rank - 1))
+                nxt = rank + 1 if lanes is None else (lanes[lane + 1] if lane + 1 < n_lanes else world)
+                prv = rank - 1 if lanes is None else (lanes[lane - 1] if lane > 0 else -1)
+                if nxt < world:
+                    ops.append(dist.P2POp(dist.isend, handoff_send, nxt))
+                if prv >= 0:
+                    ops.append(dist.P2POp(dist.irecv, handoff_recv, prv))
                 if ops:
                     for w in dist.batch_isend_irecv(ops):
                         w.wait()
@@ -208,10 +227,10 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         chunk_s = 204.0 * elapsed / args.steps
-        value = world * 21.0 / chunk_s
+        value = n_lanes * 21.0 / chunk_s
         stage_flops = [dit_forward_flops(cfg, S, q, kv) for q, kv in T2V_STAGE_SHAPES]
         chunk_flops = 102.0 * sum(stage_flops)
-        step_flops = 2.0 * sum(stage_flops) / 4.0                       # mean over the rotation, 2 forwards per step
+        step_flops = (2.0 if pair is None else 1.0) * sum(stage_flops) / 4.0   # mean over the rotation, forwards per rank-step
         achieved_pf = step_flops / (elapsed / args.steps) / 1e15
         res = {
             "metric": "video_latent_frames_per_sec", "value": value, "unit": "latent-frames/s", "n_gpus": world,
@@ -220,7 +239,9 @@ def main():
             "config": {"workload": f"Wan2.1-T2V-{args.model} {args.res} chunk-AR denoise step (cond+uncond DiT forward, CFG, UniPC), "
                                    f"rotating T2V stages s0..s3; one 21-latent-frame chunk per GPU = 204 step-equivalents",
                        "frame_seqlen": S, "latent_hw": [lat_h, lat_w], "sampling_steps": 50, "guidance_scale": 5.0,
-                       "parallelism": f"chunk-per-rank x{world}" + (" + RCCL p2p anchor hand-off r->r+1" if world > 1 else "")},
+                       "parallelism": (f"chunk-per-rank x{world}" if pair is None else f"{n_lanes} chunk lanes x 2 (cond|uncond) CFG split, "
+                                       "per-step 2-rank all-gather of flow predictions") +
+                                      (" + RCCL p2p anchor hand-off lane->lane+1" if world > 1 else "")},
             "sec_per_denoise_step": elapsed / args.steps,
             "sec_per_chunk_extrapolated": chunk_s,
             "achieved_pflops_per_gpu": achieved_pf,

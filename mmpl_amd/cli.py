@@ -20,7 +20,8 @@ import torch
 import yaml
 
 from .geometry import Geometry
-from .handoff import ChunkHandoff, handoff_to_initial_latent, rolling_initial_latent, run_chunk_wavefront, stitch_chunks
+from .handoff import (CfgPair, ChunkHandoff, handoff_to_initial_latent, rolling_initial_latent, run_chunk_wavefront,
+                      stitch_chunks)
 from .synthetic import WAN_CONFIGS, dit_state_dict, vae_state_dict
 
 DEFAULTS = dict(num_train_timestep=1000, timestep_shift=5.0, guidance_scale=5.0, independent_first_frame=False,
@@ -58,6 +59,9 @@ def main(argv=None):
     ap.add_argument("--synthetic", action="store_true", help="seeded synthetic weights / text embeddings (no checkpoints needed)")
     ap.add_argument("--sampling_steps", type=int, default=50)
     ap.add_argument("--latent_hw", type=int, nargs=2, default=None, help="override the latent size (tests)")
+    ap.add_argument("--cfg_split", action="store_true",
+                    help="multi-GPU: WORLD/2 chunk lanes x (cond, uncond) rank pairs -- the reference's device_cond/device_uncond "
+                         "seam -- instead of WORLD chunk lanes")
     args = ap.parse_args(argv)
 
     import torch.distributed as dist
@@ -115,7 +119,11 @@ def main(argv=None):
                 initial = rolling_initial_latent(pipe.vae, video)
                 videos.append(video.cpu())
         else:
-            ho = ChunkHandoff((1, 3 if args.i2v else 8, 16, geo.lat_h, geo.lat_w), dev)
+            pair, heads, lay = (CfgPair.build(world, dev, True) if args.cfg_split else (None, None, None))
+            pipe.cfg_pair = pair
+            rank = dist.get_rank()
+            ho = (ChunkHandoff((1, 3 if args.i2v else 8, 16, geo.lat_h, geo.lat_w), dev, group=heads)
+                  if pair is None or pair.role == 0 else None)
 
             def make_chunk(c, initial, sink):
                 pipe.handoff_sink = sink
@@ -124,7 +132,9 @@ def main(argv=None):
                 video, _ = pipe.inference(noises[c].to(dev), [prompt], initial_latent=initial, return_latents=True)
                 return video
 
-            videos = run_chunk_wavefront(make_chunk, args.duration, ho, lambda t: handoff_to_initial_latent(pipe.vae, t.to(dev)))
+            videos = run_chunk_wavefront(make_chunk, args.duration, ho, lambda t: handoff_to_initial_latent(pipe.vae, t.to(dev)),
+                                         pair=pair, lane=lay["lane_of"][rank] if lay else rank, n_lanes=world // 2 if lay else world,
+                                         initial_like=torch.empty([1, 2, 16, geo.lat_h, geo.lat_w], device=dev, dtype=torch.bfloat16))
         if videos is not None:
             full = stitch_chunks(videos)                                     # [1, T, 3, H, W] in [0, 1]
             out = (full[0].permute(0, 2, 3, 1) * 255.0).clamp(0, 255).to(torch.uint8)

@@ -47,8 +47,81 @@ def stitch_chunks(videos: Sequence[torch.Tensor], num_overlap_frames: int = 2) -
     return torch.cat([v if i == 0 else v[:, drop:] for i, v in enumerate(videos)], dim=1)
 
 
+def wavefront_layout(world: int, cfg_split: bool):
+    """rank -> (lane, role) and the rank lists of every group, for `world` ranks of one node.
+
+    cfg_split=False: `world` chunk lanes, one rank each (chunk c on lane c % world).
+    cfg_split=True : world/2 lanes of two ranks (2l, 2l+1) = (cond, uncond) -- the reference's device_cond/device_uncond
+    seam (casual_fps_inference.py:42-43).  The wavefront is only ~3.1 chunks deep, so 8 GPUs are used
+    as 4 lanes x 2 rather than 8 lanes.  Returns dict(lanes=[[ranks]], lane_of=[...], role_of=[...], heads=[...])."""
+    if cfg_split:
+        if world % 2:
+            raise ValueError("cfg_split needs an even number of ranks")
+        lanes = [[2 * i, 2 * i + 1] for i in range(world // 2)]
+    else:
+        lanes = [[r] for r in range(world)]
+    lane_of = [0] * world
+    role_of = [0] * world
+    for li, ranks in enumerate(lanes):
+        for role, r in enumerate(ranks):
+            lane_of[r], role_of[r] = li, role
+    return dict(lanes=lanes, lane_of=lane_of, role_of=role_of, heads=[ranks[0] for ranks in lanes])
+
+
+class CfgPair:
+    """The two ranks that share one chunk: role 0 runs the conditional branch, role 1 the unconditional one.
+
+    exchange(): one all-gather of the two flow predictions ([nF,16,h,w] bf16 each, <= 3.2 MB at 720p) per denoise step
+    over the pair's xGMI link; broadcast(): role 0's tensor to role 1 (noise, re-noise draws, initial latents)."""
+
+    def __init__(self, ranks: Sequence[int], group, device):
+        import torch.distributed as dist
+        self.dist, self.group, self.ranks = dist, group, list(ranks)
+        self.role = self.ranks.index(dist.get_rank())
+        self.backend = dist.get_backend(group)
+        self.device = torch.device("cpu") if self.backend == "gloo" else torch.device(device)
+
+    @classmethod
+    def build(cls, world: int, device, cfg_split: bool = True):
+        """Collective over ALL ranks (every rank creates every group, as torch.distributed requires).
+        Returns (pair or None, lane_heads_group, layout)."""
+        import torch.distributed as dist
+        lay = wavefront_layout(world, cfg_split)
+        me = dist.get_rank()
+        pair = None
+        if cfg_split:
+            for ranks in lay["lanes"]:
+                g = dist.new_group(ranks)
+                if me in ranks:
+                    pair = cls(ranks, g, device)
+        heads = dist.new_group(lay["heads"]) if cfg_split else None
+        return pair, heads, lay
+
+    def exchange(self, mine: torch.Tensor, both: torch.Tensor) -> torch.Tensor:
+        """both[role] <- the flow prediction of that role, on both ranks.  `both`: [2, *mine.shape]."""
+        assert both.shape[0] == 2 and both.shape[1:] == mine.shape
+        if self.backend == "gloo":
+            m = mine.cpu() if mine.device.type != "cpu" else mine
+            parts = [torch.empty_like(m), torch.empty_like(m)]
+            self.dist.all_gather(parts, m.contiguous(), group=self.group)
+            both[0].copy_(parts[0])
+            both[1].copy_(parts[1])
+        else:
+            self.dist.all_gather_into_tensor(both, mine, group=self.group)
+        return both
+
+    def broadcast(self, t: torch.Tensor) -> torch.Tensor:
+        if self.backend == "gloo" and t.device.type != "cpu":
+            c = t.cpu()
+            self.dist.broadcast(c, src=self.ranks[0], group=self.group)
+            return t.copy_(c)
+        self.dist.broadcast(t, src=self.ranks[0], group=self.group)
+        return t
+
+
 class ChunkHandoff:
-    """Point-to-point anchor exchange between the ranks of one node."""
+    """Point-to-point anchor exchange between the ranks of one node (or of `group`, e.g. the lane heads of a CFG-split
+    layout; ranks inside the group are translated to global ranks for the p2p calls)."""
 
     def __init__(self, shape: Sequence[int], device, group=None):
         import torch.distributed as dist
@@ -59,6 +132,7 @@ class ChunkHandoff:
         self.backend = dist.get_backend(group)
         self.device = torch.device("cpu") if self.backend == "gloo" else torch.device(device)
         self.shape = tuple(shape)
+        self._g = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
         self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self._pending: List = []
 
@@ -67,11 +141,12 @@ class ChunkHandoff:
 
     def send(self, chunk: int, tensor: Optional[torch.Tensor], status: int = OK) -> None:
         """Send chunk `chunk`'s hand-off to the owner of chunk+1 (asynchronous; overlaps the caller's next stage)."""
-        dst = self.owner(chunk + 1)
+        dst_local = self.owner(chunk + 1)
+        dst = self._g(dst_local)
         hdr = torch.tensor([status, chunk], dtype=torch.int64, device=self.device)
         payload = (torch.zeros(self.shape, dtype=torch.bfloat16, device=self.device) if tensor is None
                    else tensor.detach().to(device=self.device, dtype=torch.bfloat16).reshape(self.shape).contiguous())
-        if dst == self.rank:                                   # world size 1 (or wrap onto ourselves): local hand-over
+        if dst_local == self.rank:                             # world size 1 (or wrap onto ourselves): local hand-over
             self._local = (hdr, payload)
             return
         if self._side is not None:
@@ -87,8 +162,9 @@ class ChunkHandoff:
     def recv(self, chunk: int) -> torch.Tensor:
         """Receive the hand-off produced by chunk-1.  Bounded by the process group's timeout; raises if the producer
         reported failure."""
-        src = self.owner(chunk - 1)
-        if src == self.rank:
+        src_local = self.owner(chunk - 1)
+        src = self._g(src_local)
+        if src_local == self.rank:
             hdr, payload = self._local
         else:
             hdr = torch.zeros(2, dtype=torch.int64, device=self.device)
@@ -109,13 +185,22 @@ class ChunkHandoff:
 
 
 def run_chunk_wavefront(make_chunk: Callable[[int, Optional[torch.Tensor], Callable[[torch.Tensor], None]], torch.Tensor],
-                        n_chunks: int, handoff: ChunkHandoff, to_initial: Callable[[torch.Tensor], torch.Tensor],
-                        gather: bool = True) -> Optional[List[torch.Tensor]]:
+                        n_chunks: int, handoff: Optional[ChunkHandoff], to_initial: Callable[[torch.Tensor], torch.Tensor],
+                        gather: bool = True, pair: Optional[CfgPair] = None, lane: int = 0, n_lanes: int = 1,
+                        initial_like: Optional[torch.Tensor] = None) -> Optional[List[torch.Tensor]]:
     """Chunk c runs on rank c % W (the reference's pipeline k <-> cuda:k and its round-robin,
     Wan_fps_inference_parallel_4gpu_5-60s.py:252-332).
 
     make_chunk(c, initial_latent_or_None, sink) must call sink(handoff_tensor) once the anchor stage is done and return
-    the chunk's result tensor.  Returns the list of all chunk results on rank 0 (None elsewhere) when gather=True."""
+    the chunk's result tensor.  Returns the list of all chunk results on rank 0 (None elsewhere) when gather=True.
+
+    CFG-split lanes: the lane heads (pair.role == 0) run exactly the loop above over `handoff` (built on the heads
+    group); their uncond partners (pair.role == 1, handoff=None) run the same chunks of lane `lane` of `n_lanes` with a
+    placeholder `initial_like` that the pipeline overwrites with the head's broadcast, and take no part in the gather."""
+    if pair is not None and pair.role != 0:
+        for c in range(lane, n_chunks, n_lanes):
+            make_chunk(c, None if c == 0 else torch.empty_like(initial_like), lambda t: None)
+        return None
     dist = handoff.dist
     mine = {}
     for c in range(handoff.rank, n_chunks, handoff.world):

@@ -10,7 +10,11 @@ underneath, MI355X-first:
   * nothing is shuffled to the CPU (T5 / VAE stay resident: 288 GB HBM);
   * the literals 1560 / 40x128 / 40 blocks are derived from a ``Geometry`` and the model config;
   * the hand-off is delivered to ``self.handoff_sink`` (default: ``torch.save(self.save)`` like the reference; the
-    multi-GPU runner installs an RCCL send, mmpl_amd/handoff.py).
+    multi-GPU runner installs an RCCL send, mmpl_amd/handoff.py);
+  * the reference's ``device_cond`` / ``device_uncond`` seam (two GPUs per pipeline, :42-43,346-367) is ``self.cfg_pair``
+    in the one-process-per-GPU world: the two ranks of a ``CfgPair`` each own ONE branch (cond or uncond: its KV cache,
+    cross-attention cache and forward), exchange the two flow predictions per step (one 2-rank all-gather of <= 3.2 MB)
+    and both apply the fused CFG + UniPC update, so their latents stay bit-identical without a second exchange.
 """
 from __future__ import annotations
 
@@ -60,6 +64,7 @@ class CausalFPSInferencePipeline(torch.nn.Module):
         self.handoff_sink: Optional[Callable[[torch.Tensor], None]] = None
         self.renoise_override = None      # tests: {frame: [1,16,h,w]} instead of torch.randn_like draws
         self.use_graphs = True            # one hipGraph per (stage, cond|uncond) forward, replayed 50 + 1 times
+        self.cfg_pair = None              # mmpl_amd.handoff.CfgPair: this rank runs only the cond (role 0) / uncond (role 1) branch
 
         # ---- "add new noise on previous frames" schedule (casual_fps_inference.py:93-108); the randint keeps the
         # reference's RNG consumption order; the resulting timestep is >= 1000, i.e. pure noise
@@ -78,10 +83,15 @@ class CausalFPSInferencePipeline(torch.nn.Module):
         return self.generator_cond(noisy_image_or_video=latents, conditional_dict=cond, timestep=timestep, kv_cache=kv,
                                    crossattn_cache=cross, current_start=starts, cache_start=starts, out=out)[0]
 
+    def _branches(self, cond, uncond):
+        """[(conditional_dict, kv_cache, crossattn_cache, index into the flow pair)] this rank computes."""
+        b = [(cond, self.kv_cache_pos, self.crossattn_cache_pos, 0), (uncond, self.kv_cache_neg, self.crossattn_cache_neg, 1)]
+        return b if self.cfg_pair is None else [b[self.cfg_pair.role]]
+
     def _refresh(self, latents, cond, uncond, timestep, frames):
         """rerun with timestep zero to update the KV cache with clean context (:385-403)."""
-        self._forward(latents, cond, timestep * 0, self.kv_cache_pos, self.crossattn_cache_pos, frames)
-        self._forward(latents, uncond, timestep * 0, self.kv_cache_neg, self.crossattn_cache_neg, frames)
+        for d, kv, cross, _ in self._branches(cond, uncond):
+            self._forward(latents, d, timestep * 0, kv, cross, frames)
 
     def inference(self, noise: torch.Tensor, text_prompts: List[str], initial_latent: Optional[torch.Tensor] = None,
                   return_latents: bool = False, start_frame_index: Optional[int] = 0, decode: bool = True):
@@ -90,22 +100,34 @@ class CausalFPSInferencePipeline(torch.nn.Module):
         batch_size, num_frames, num_channels, height, width = noise.shape
         assert batch_size == 1 and num_frames == self.geometry.frames_per_chunk
         dev = noise.device
+        pair = self.cfg_pair
         with torch.no_grad():
-            conditional_dict = self.text_encoder(text_prompts=text_prompts)
-            unconditional_dict = self.text_encoder(text_prompts=[self.args.negative_prompt] * len(text_prompts))
+            if pair is not None:                                              # same noise on both ranks of the pair
+                noise = pair.broadcast(noise.contiguous())
+                if initial_latent is not None:
+                    initial_latent = pair.broadcast(initial_latent.to(device=dev, dtype=noise.dtype).contiguous())
+            # each branch needs only its own prompt embedding (the T5 runs once per rank in a CfgPair)
+            conditional_dict = (self.text_encoder(text_prompts=text_prompts) if pair is None or pair.role == 0 else None)
+            unconditional_dict = (self.text_encoder(text_prompts=[self.args.negative_prompt] * len(text_prompts))
+                                  if pair is None or pair.role == 1 else None)
 
             output = torch.zeros_like(noise)
-            if self.kv_cache_pos is None:
-                self.kv_cache_pos = self.generator_cond.new_kv_cache()
-                self.kv_cache_neg = self.generator_cond.new_kv_cache()
-                self.crossattn_cache_pos = self.generator_cond.new_crossattn_cache()
-                self.crossattn_cache_neg = self.generator_cond.new_crossattn_cache()
+            want_pos, want_neg = pair is None or pair.role == 0, pair is None or pair.role == 1
+            if self.kv_cache_pos is None and self.kv_cache_neg is None:
+                if want_pos:
+                    self.kv_cache_pos = self.generator_cond.new_kv_cache()
+                    self.crossattn_cache_pos = self.generator_cond.new_crossattn_cache()
+                if want_neg:
+                    self.kv_cache_neg = self.generator_cond.new_kv_cache()
+                    self.crossattn_cache_neg = self.generator_cond.new_crossattn_cache()
             else:
                 for c in (self.crossattn_cache_pos, self.crossattn_cache_neg):
-                    for blk in c:
+                    for blk in (c or []):
                         blk["is_init"] = False
-                self.kv_cache_pos.reset()
-                self.kv_cache_neg.reset()
+                for kv in (self.kv_cache_pos, self.kv_cache_neg):
+                    if kv is not None:
+                        kv.reset()
+            live_kv = [kv for kv in (self.kv_cache_pos, self.kv_cache_neg) if kv is not None]
 
             stages = self.plan.stages
             S = self.frame_seq_length
@@ -135,48 +157,54 @@ class CausalFPSInferencePipeline(torch.nn.Module):
                         sl = slice(0, 1) if pos == 0 else slice(-1, None)
                         fresh = (torch.randn_like(latents[:, sl]) if self.renoise_override is None else
                                  self.renoise_override[frames[pos]].to(latents).unsqueeze(1))
+                        if pair is not None:
+                            fresh = pair.broadcast(fresh.contiguous())        # one RNG draw per pair, not per rank
                         latents[:, sl] = self.ddpm_scheduler.add_noise(
                             output[:, s:s + 1].flatten(0, 1), fresh.flatten(0, 1),
                             self.ddmp_timestep.flatten(0, 1)).unflatten(0, (1, 1))
                 if self.plan.hides_anchors(si):
-                    for cache in (self.kv_cache_pos, self.kv_cache_neg):
+                    for cache in live_kv:
                         for v in (20 * S, 19 * S):
                             if v in cache.vis:
                                 cache.vis.remove(v)
                 elif self.plan.shows_anchors(si):
-                    for cache in (self.kv_cache_pos, self.kv_cache_neg):
+                    for cache in live_kv:
                         for v in (20 * S, 19 * S):
                             if v not in cache.vis:
                                 cache.vis.append(v)
 
                 sample_scheduler = self._initialize_sample_scheduler(noise)
-                flow_c = torch.empty_like(latents)
-                flow_u = torch.empty_like(latents)
+                flow = torch.empty((2,) + tuple(latents.shape), device=dev, dtype=latents.dtype)   # [cond, uncond]
+                branches = self._branches(conditional_dict, unconditional_dict)
+                # in a CfgPair the forward writes a private buffer and the all-gather fills both halves of `flow`
+                outs = [flow[i] for _, _, _, i in branches] if pair is None else [torch.empty_like(latents)]
                 timestep = torch.empty([1, len(frames)], device=dev, dtype=torch.float32)
                 graphs = None
                 if self.use_graphs:
                     starts = [f * S for f in frames]
                     timestep.fill_(float(sample_scheduler.timesteps[0]))
-                    graphs = (self.generator_cond.capture(latents, conditional_dict, timestep, self.kv_cache_pos,
-                                                          self.crossattn_cache_pos, starts, flow_c),
-                              self.generator_cond.capture(latents, unconditional_dict, timestep, self.kv_cache_neg,
-                                                          self.crossattn_cache_neg, starts, flow_u))
+                    graphs = [self.generator_cond.capture(latents, d, timestep, kv, cross, starts, o)
+                              for (d, kv, cross, _), o in zip(branches, outs)]
                 for t in sample_scheduler.timesteps:
                     timestep.fill_(float(t))
                     if graphs is not None:
-                        graphs[0].replay()
-                        graphs[1].replay()
+                        for g in graphs:
+                            g.replay()
                     else:
-                        self._forward(latents, conditional_dict, timestep, self.kv_cache_pos, self.crossattn_cache_pos, frames, flow_c)
-                        self._forward(latents, unconditional_dict, timestep, self.kv_cache_neg, self.crossattn_cache_neg, frames, flow_u)
+                        for (d, kv, cross, _), o in zip(branches, outs):
+                            self._forward(latents, d, timestep, kv, cross, frames, o)
+                    if pair is not None:
+                        pair.exchange(outs[0], flow)
                     # flow = uncond + g (cond - uncond); latents = scheduler.step(flow)  -- one fused kernel (:366-374)
-                    sample_scheduler.step_cfg(flow_c, flow_u, self.args.guidance_scale, latents)
+                    sample_scheduler.step_cfg(flow[0], flow[1], self.args.guidance_scale, latents)
 
                 output[:, frames] = latents
                 if si == self.plan.handoff_stage:                             # t2v :380-383, i2v :340-343
                     save_latents = (torch.cat([output[:, :1], latents], dim=1) if self.mode == "t2v"
                                     else torch.cat([output[:, :1], output[:, -2:]], dim=1))
-                    if self.handoff_sink is not None:
+                    if pair is not None and pair.role != 0:
+                        pass                                                  # the cond rank of the pair delivers it
+                    elif self.handoff_sink is not None:
                         self.handoff_sink(save_latents)
                     elif self.save:
                         torch.save(save_latents, self.save)
@@ -186,13 +214,13 @@ class CausalFPSInferencePipeline(torch.nn.Module):
                     pass
                 elif graphs is not None:                                        # refresh pass = same graphs at t = 0
                     timestep.zero_()
-                    graphs[0].replay()
-                    graphs[1].replay()
+                    for g in graphs:
+                        g.replay()
                 else:
                     self._refresh(latents, conditional_dict, unconditional_dict, timestep, frames)
 
             video = None
-            if decode:
+            if decode and (pair is None or pair.role == 0):
                 video = self.vae.decode_to_pixel(output)
                 video = (video * 0.5 + 0.5).clamp(0, 1)
         if return_latents:

@@ -1,0 +1,96 @@
+"""CFG-split lanes on CPU (gloo, world_size 4 = 2 chunk lanes x (cond, uncond)): group layout, the per-step flow
+exchange, role-0 broadcasts, and the anchor hand-off between lane heads through global-rank translation."""
+import datetime
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mmpl_amd.handoff import CfgPair, ChunkHandoff, wavefront_layout
+
+SHAPE = (1, 3, 16, 4, 6)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _branch(role, lat, t):
+    """stand-in for the cond / uncond DiT forward: any deterministic function of (branch, latents, t)."""
+    return (torch.sin(lat.float() * (1.0 + role)) * (0.5 + t)).to(torch.bfloat16)
+
+
+def _denoise(lat, steps, flows):
+    for i in range(steps):
+        c, u = flows(lat, i)
+        lat = (lat.float() - 0.1 * (u.float() + 5.0 * (c.float() - u.float()))).to(torch.bfloat16)
+    return lat
+
+
+def _worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        pair, heads, lay = CfgPair.build(world, "cpu", cfg_split=True)
+        lane = lay["lane_of"][rank]
+        assert pair.role == lay["role_of"][rank] == rank % 2 and pair.ranks == [2 * lane, 2 * lane + 1]
+        # role 0 draws the noise; role 1 must end up with the same tensor
+        g = torch.Generator().manual_seed(100 + rank)
+        noise = pair.broadcast(torch.randn(2, 16, 4, 6, generator=g).to(torch.bfloat16))
+
+        def flows(lat, i):
+            mine = _branch(pair.role, lat, i / 4)
+            both = torch.empty((2,) + tuple(lat.shape), dtype=lat.dtype)
+            pair.exchange(mine, both)
+            return both[0], both[1]
+
+        lat = _denoise(noise.clone(), 4, flows)
+        # lane heads chain the anchor hand-off (lane 0 -> lane 1) over the heads group
+        got = None
+        if pair.role == 0:
+            ho = ChunkHandoff(SHAPE, "cpu", group=heads)
+            assert ho.world == world // 2 and ho.rank == lane
+            if lane == 0:
+                ho.send(0, torch.full(SHAPE, 7.0))
+            else:
+                got = ho.recv(1)
+            ho.flush()
+        if lane == 1:                                       # ... and the head forwards it to its uncond partner
+            got = pair.broadcast(got if pair.role == 0 else torch.empty(SHAPE, dtype=torch.bfloat16))
+        torch.save({"noise": noise, "lat": lat, "got": got}, f"{out_path}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_layout():
+    lay = wavefront_layout(8, True)
+    assert lay["lanes"] == [[0, 1], [2, 3], [4, 5], [6, 7]] and lay["heads"] == [0, 2, 4, 6]
+    assert lay["lane_of"] == [0, 0, 1, 1, 2, 2, 3, 3] and lay["role_of"] == [0, 1] * 4
+    lay = wavefront_layout(4, False)
+    assert lay["lanes"] == [[0], [1], [2], [3]] and lay["role_of"] == [0] * 4
+    with pytest.raises(ValueError):
+        wavefront_layout(3, True)
+
+
+def test_cfg_pairs_two_lanes(tmp_path):
+    out = str(tmp_path / "o")
+    mp.spawn(_worker, args=(4, _free_port(), out), nprocs=4, join=True)
+    r = [torch.load(f"{out}.{k}") for k in range(4)]
+    for lane in range(2):
+        a, b = r[2 * lane], r[2 * lane + 1]
+        assert torch.equal(a["noise"], b["noise"])
+        assert torch.equal(a["lat"], b["lat"])              # both ranks of a pair hold bit-identical latents
+        # == the single-process loop that runs both branches itself
+        want = _denoise(a["noise"].clone(), 4, lambda lat, i: (_branch(0, lat, i / 4), _branch(1, lat, i / 4)))
+        assert torch.equal(a["lat"], want)
+    assert not torch.equal(r[0]["noise"], r[2]["noise"])
+    assert r[0]["got"] is None and r[1]["got"] is None
+    assert torch.equal(r[2]["got"], torch.full(SHAPE, 7.0, dtype=torch.bfloat16)) and torch.equal(r[3]["got"], r[2]["got"])
