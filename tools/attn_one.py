@@ -1,0 +1,39 @@
+"""One attention launch population for rocprofv3 --pmc (dev tool): python3 tools/attn_one.py [stage] [iters]"""
+import ctypes as C
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mmpl_amd import _lib  # noqa: E402
+
+lib = _lib.load()
+dev = "cuda:0"
+BF = torch.bfloat16
+stage = sys.argv[1] if len(sys.argv) > 1 else "s1"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+nq, npg = {"s0": (2, 2), "s1": (7, 9), "s2": (6, 13), "s3": (6, 21)}[stage]
+H, S, d = 40, 3600, 5120
+kc = torch.randn(npg * S, d, device=dev).to(BF)
+vc = torch.randn(npg * S, d, device=dev).to(BF)
+Lq = nq * S
+q = torch.randn(Lq, 3 * d, device=dev).to(BF)
+o = torch.empty(Lq, d, device=dev, dtype=BF)
+kp = (C.c_void_p * npg)(*[kc[i * S:].data_ptr() for i in range(npg)])
+vp = (C.c_void_p * npg)(*[vc[i * S:].data_ptr() for i in range(npg)])
+dbg = torch.zeros(64 * 8 * 8, dtype=torch.int64, device=dev)
+os.environ["MMPL_ATTN_DBG"] = str(dbg.data_ptr())
+for _ in range(iters):
+    _lib.check(lib.mmpl_attn_fwd(_lib.ptr(q), 3 * d, _lib.ptr(o), d, kp, vp, d, d, npg, S, Lq, H, 1 / math.sqrt(128), _lib.stream_ptr()))
+torch.cuda.synchronize()
+print("done", stage, float(o.float().abs().mean()))
+if os.environ.get("MMPL_ATTN_V") in ("9", "10", "11", "12", "13", "14", "15", "16", "18"):
+    d = dbg.cpu().view(64, 8, 8).double()
+    T = d[0, 0, 3].item()
+    print("tiles", T)
+    for name, i in (("M", 0), ("V", 1), ("B", 2)):
+        per = d[:, :, i] / T
+        print(f"{name}: grpA mean {per[:, :4].mean():.0f}  grpB mean {per[:, 4:].mean():.0f}  min {per.min():.0f} max {per.max():.0f}")
+    print("per-wave block0:", (d[0, :, :3] / T).round().tolist())
