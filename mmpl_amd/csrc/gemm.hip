@@ -394,7 +394,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// v4 (default for large problems): v3 geometry with BK = 64 and a 2-stage ring (2 x 64 KiB): half as many barriers per MFMA, the DMA of
+// v4 (MMPL_GEMM_V4=1; the lock-step predecessor of v6): v3 geometry with BK = 64 and a 2-stage ring (2 x 64 KiB): half as many barriers per MFMA, the DMA of
 // tile t+1 has one whole iteration (64 MFMAs per wave) to land; plain vmcnt(0) + raw barrier per tile.
 constexpr int BK4 = 64, A4_BYTES = BM3 * BK4 * 2, STAGE4 = 2 * A4_BYTES;
 MMPL_DEV int swz64(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
@@ -482,6 +482,146 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   gemm_epilogue<EPI>(g, acc[1], m0 + 128 * wm + 64, n0 + 64 * wn, frow, fchunk);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// v6 "ping-pong" (default for large problems): v4's tile (256x256x64, 8 waves 2x4, 2-stage LDS-DMA ring) with the two wave groups (waves 0-3 / 4-7:
+// waves w and w+4 share a SIMD) running half a k-tile apart.  Per k-tile a wave runs
+//   R_t = { request its 24 LDS fragments of tile t (+ group A: issue ALL 64 LDS-DMA ops of tile t+1) }
+//   M_t = { 64 MFMAs }
+// and while one group is in M the other is in R, so each SIMD's matrix pipe is fed by one wave while its partner's
+// LDS reads / DMA issue stalls happen in the shadow, instead of both waves reading, then both multiplying (v4).
+// A DMA op is global_load_lds_dwordx4 voff, s[base] with voff = (clamped row * ld + swizzled chunk) * 2: needs
+// M * lda * 2 and N * ldw * 2 < 4 GiB (checked by the launcher, else v4).  Bit-identical to v4 (same MFMA order);
+// measured in one process on the 14B/720p shapes: +4 ... +14 % over v4 (1220-1290 vs 1070-1200 TFLOP/s, 1415 vs 1310
+// at 8192^3).  With the DMA ops removed the same kernel runs at 1450-1470: the LDS-DMA issue stalls (~100 cycles per
+// op) are the remaining cost.  A BK = 32 / 4-deep-ring variant in which both groups issue their own DMA ops inside
+// their R segments was slower (twice the barriers: 1040-1150).
+MMPL_DEV void glds16s(const void* base, uint32_t voff, char* lds) {
+  const uint32_t dst = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)lds);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(dst) : "memory");
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_v6_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tiles_m = (g.M + BM3 - 1) / BM3, tiles_n = (g.N + BN3 - 1) / BN3;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int GROUP = g.group;
+  const int per_group = GROUP * tiles_n;
+  const int gid = bid / per_group;
+  const int first_m = gid * GROUP;
+  const int gsz = min(tiles_m - first_m, GROUP);
+  const int tm = first_m + (bid % per_group) % gsz;
+  const int tn = (bid % per_group) / gsz;
+  const int m0 = tm * BM3, n0 = tn * BN3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3, grp = wave >> 2;
+
+  // ---- DMA (group A only): wave w issues pieces 4q + w, q = 0..15 (q < 8: A rows 8*(4q+w).., q >= 8: W rows)
+  const int lr = lane >> 3, lc = ((lane & 7) ^ (lr & 7)) << 3;     // row within the piece, swizzled source chunk (elements)
+  const bf16_t* a_k = g.A;                                         // advance by BK4 elements per tile
+  const bf16_t* w_k = g.W;
+  auto issue_piece = [&](int q, char* st) {
+    const bool isw = q >= 8;
+    const int p = 4 * (q & 7) + wave;                              // piece of the A (or W) tile: rows 8p .. 8p+7
+    const int row = isw ? min(n0 + 8 * p + lr, g.N - 1) : min(m0 + 8 * p + lr, g.M - 1);
+    const uint32_t voff = (uint32_t)(row * (isw ? g.ldw : g.lda) + lc) * 2u;
+    glds16s(isw ? w_k : a_k, voff, st + (isw ? A4_BYTES : 0) + p * 1024);
+  };
+
+  f32x4 acc[2][4][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fchunk = lane >> 4;
+  int a_off[8], w_off[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a_off[i] = swz64(128 * wm + 16 * i + frow, fchunk);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w_off[i] = A4_BYTES + swz64(64 * wn + 16 * i + frow, fchunk);
+  const int nt = g.K / BK4;
+
+  if (grp == 0) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) issue_piece(q, smem);
+    a_k += BK4;
+    w_k += BK4;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();          // group B runs half a tile late
+
+  for (int t = 0; t < nt; ++t) {
+    // =========================== R_t
+    const char* st = smem + (t & 1) * STAGE4;
+    char* nx = smem + ((t + 1) & 1) * STAGE4;
+    const bool do_issue = grp == 0 && t + 1 < nt;
+    bf16x8 af[2][8], wf[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        wf[ks][i] = *reinterpret_cast<const bf16x8*>(st + (w_off[i] ^ (ks << 6)));
+        if (do_issue) issue_piece(ks * 8 + i, nx);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        af[ks][i] = *reinterpret_cast<const bf16x8*>(st + (a_off[i] ^ (ks << 6)));
+        if ((i & 1) && do_issue) issue_piece(ks * 8 + 4 + (i >> 1), nx);
+      }
+    }
+    if (do_issue) { a_k += BK4; w_k += BK4; }
+    // the fragments are complete HERE (hipcc would otherwise sink the reads next to their MFMAs, into the M segment)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      asm volatile("" : "+v"(af[ks][0]), "+v"(af[ks][1]), "+v"(af[ks][2]), "+v"(af[ks][3]), "+v"(af[ks][4]), "+v"(af[ks][5]),
+                        "+v"(af[ks][6]), "+v"(af[ks][7]), "+v"(wf[ks][0]), "+v"(wf[ks][1]), "+v"(wf[ks][2]), "+v"(wf[ks][3]));
+    }
+    __builtin_amdgcn_s_barrier();
+    // =========================== M_t
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i >> 2][i & 3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[i >> 2][i & 3][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t+1 landed before anyone reads it
+    __builtin_amdgcn_s_barrier();
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+  gemm_epilogue<EPI>(g, acc[0], m0 + 128 * wm, n0 + 64 * wn, frow, fchunk);
+  gemm_epilogue<EPI>(g, acc[1], m0 + 128 * wm + 64, n0 + 64 * wn, frow, fchunk);
+}
+
+template <int EPI>
+hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
+  static bool attr_set = false;
+  constexpr int smem = 2 * STAGE4;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_v6_kernel<EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int tiles = ((g.M + BM3 - 1) / BM3) * ((g.N + BN3 - 1) / BN3);
+  GemmArgs g2 = g;
+  g2.group = 4;
+  hipLaunchKernelGGL(gemm_bf16_v6_kernel<EPI>, dim3(tiles), dim3(512), smem, s, g2);
+  return hipGetLastError();
+}
+
 template <int EPI>
 hipError_t launch_v4(const GemmArgs& g, hipStream_t s) {
   static bool attr_set = false;
@@ -536,6 +676,7 @@ template <int EPI>
 hipError_t launch(const GemmArgs& g, hipStream_t s) {
   const bool big = g.batch <= 1 && g.M >= 1024 && g.N >= 256 && g.K >= 128 && !getenv("MMPL_GEMM_V1") && !getenv("MMPL_GEMM_V2");
   if (big && getenv("MMPL_GEMM_V3")) return launch_v3<EPI>(g, s);
+  if (big && !getenv("MMPL_GEMM_V4") && (long long)g.M * g.lda < (1ll << 31) && (long long)g.N * g.ldw < (1ll << 31)) return launch_v6<EPI>(g, s);
   if (big) return launch_v4<EPI>(g, s);
   if (g.batch <= 1 && g.M >= 1024 && g.N >= 128 && g.K >= 128 && !getenv("MMPL_GEMM_V1")) return launch_v2<EPI>(g, s);
   static bool attr_set = false;
