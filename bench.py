@@ -251,9 +251,18 @@ def main():
         if prof and "attn_self" in prof:
             a = prof["attn_self"]
             ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
-            res["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel (self-attention over the KV-slot page table)",
+            traffic, traffic_src = None, None
+            pmc = os.path.join(ROOT, "profiles", "r01f_pmc_attention_hbm.json")
+            if args.model == "14B" and args.res == "720p" and os.path.exists(pmc):
+                # HBM bytes per launch cannot be collected inside this process (rocprofv3 --pmc wraps the program): the
+                # committed PMC passes of the same kernel on the same four launch shapes, averaged over the rotation
+                st = json.load(open(pmc))["stages"]
+                traffic = sum(st[k]["hbm_bytes"] for k in ("s0", "s1", "s2", "s3")) / 4.0
+                traffic_src = "profiles/r01f_pmc_attention_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, mean of s0..s3)"
+            res["roofline"] = {"bound": "mfma", "kernel": "attn_pp_kernel (self-attention over the KV-slot page table)",
                                "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-                               "traffic": None, "avg_launch_ms": a["ms"] / a["launches"], "launches": a["launches"],
+                               "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+                               "avg_launch_ms": a["ms"] / a["launches"], "launches": a["launches"],
                                "algorithmic_flops_per_launch": a["flops"] / a["launches"]}
             tot = sum(v["ms"] for v in prof.values())
             res["kernel_time_share"] = {k: round(v["ms"] / tot, 4) for k, v in prof.items()}

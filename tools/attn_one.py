@@ -23,17 +23,9 @@ q = torch.randn(Lq, 3 * d, device=dev).to(BF)
 o = torch.empty(Lq, d, device=dev, dtype=BF)
 kp = (C.c_void_p * npg)(*[kc[i * S:].data_ptr() for i in range(npg)])
 vp = (C.c_void_p * npg)(*[vc[i * S:].data_ptr() for i in range(npg)])
-dbg = torch.zeros(64 * 8 * 8, dtype=torch.int64, device=dev)
-os.environ["MMPL_ATTN_DBG"] = str(dbg.data_ptr())
+
+
 for _ in range(iters):
     _lib.check(lib.mmpl_attn_fwd(_lib.ptr(q), 3 * d, _lib.ptr(o), d, kp, vp, d, d, npg, S, Lq, H, 1 / math.sqrt(128), _lib.stream_ptr()))
 torch.cuda.synchronize()
 print("done", stage, float(o.float().abs().mean()))
-if os.environ.get("MMPL_ATTN_V") in ("9", "10", "11", "12", "13", "14", "15", "16", "18"):
-    d = dbg.cpu().view(64, 8, 8).double()
-    T = d[0, 0, 3].item()
-    print("tiles", T)
-    for name, i in (("M", 0), ("V", 1), ("B", 2)):
-        per = d[:, :, i] / T
-        print(f"{name}: grpA mean {per[:, :4].mean():.0f}  grpB mean {per[:, 4:].mean():.0f}  min {per.min():.0f} max {per.max():.0f}")
-    print("per-wave block0:", (d[0, :, :3] / T).round().tolist())
