@@ -82,8 +82,11 @@ def _attn_case(lib, Lq, H, S, n_pages, ld_mult=1, seed=0):
     return o, ref32, ref16
 
 
+# (the last row: KV streams of 1, 1 (ragged), 3, 4 and 24 (max pages, all ragged) tiles -- the prologue / ring-wrap / counted
+# s_waitcnt branches of the ping-pong kernel)
 @pytest.mark.parametrize("Lq,H,S,n_pages", [(96, 2, 96, 1), (200, 2, 100, 3), (512, 1, 512, 1), (3120, 2, 1560, 2),
-                                            (300, 8, 72, 21), (257, 3, 40, 5)])
+                                            (300, 8, 72, 21), (257, 3, 40, 5),
+                                            (64, 1, 64, 1), (130, 2, 30, 1), (100, 1, 64, 3), (70, 2, 128, 2), (256, 1, 10, 24)])
 def test_attention_paged(lib, Lq, H, S, n_pages):
     o, ref32, ref16 = _attn_case(lib, Lq, H, S, n_pages, ld_mult=3 if H == 2 else 1)
     e_kernel, e_ref = rel_l2(o, ref32), rel_l2(ref16, ref32)
