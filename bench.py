@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--model", default="14B", choices=["14B", "1.3B", "small", "tiny"])
     ap.add_argument("--res", default="720p", choices=["480p", "720p", "tiny"])
+    ap.add_argument("--mode", default="t2v", choices=["t2v", "i2v"], help="stage plan of the rotation (i2v: 1/7/6/6 query frames, BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="disable the per-kernel hipEvent pairs")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-region) VAE decode measurement")
@@ -85,7 +86,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:      # (a 1-rank torchrun launch exercises the RCCL init / barrier / all-reduce path too)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
@@ -103,7 +104,7 @@ def main():
     from mmpl_amd.dit import DitEngine
     from mmpl_amd.geometry import RESOLUTIONS
     from mmpl_amd.scheduler import FlowUniPCMultistepScheduler
-    from mmpl_amd.stage_plan import N_SLOTS, T2V_STAGE_SHAPES, StagePlan, dit_forward_flops, slot_of
+    from mmpl_amd.stage_plan import I2V_STAGE_SHAPES, N_SLOTS, T2V_STAGE_SHAPES, StagePlan, dit_forward_flops, slot_of
     from mmpl_amd.synthetic import WAN_CONFIGS, dit_state_dict
 
     lib = _lib.load()
@@ -112,7 +113,8 @@ def main():
     eng = DitEngine(cfg, lat_h, lat_w, dev)
     eng.load_state_dict(dit_state_dict(cfg, seed=1234, device=dev))
     S = eng.S
-    plan = StagePlan("t2v")
+    plan = StagePlan(args.mode)
+    stage_shapes = T2V_STAGE_SHAPES if args.mode == "t2v" else I2V_STAGE_SHAPES
 
     # two KV caches (cond / uncond) filled with unit-variance data so softmax sees realistic score spreads
     caches = []
@@ -125,9 +127,10 @@ def main():
         ck, cv = eng.precompute_context(ctx)
         caches.append((kc, vc, ck, cv))
     # per-stage state: latents, visible slots, scheduler
-    vis_frames = [[0, 1], [0, 1, 2, 3, 10, 11, 12, 19, 20], list(range(13)), list(range(13)) + [19, 20]]
+    vis_frames = [[0, 1], [0, 1, 2, 3, 10, 11, 12, 19, 20], list(range(13)) + ([] if args.mode == "t2v" else [19, 20]),
+                  list(range(13)) + [19, 20]]
     stage_state = []
-    for si, frames in enumerate(plan.stages):
+    for si, frames in enumerate(plan.stages if args.mode == "t2v" else plan.stages[1:]):
         lat = torch.randn(len(frames), 16, lat_h, lat_w, device=dev).to(torch.bfloat16)
         sched = FlowUniPCMultistepScheduler(1000, 2, 1.0)
         sched.set_timesteps(50, shift=5.0)
@@ -228,7 +231,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         chunk_s = 204.0 * elapsed / args.steps
         value = n_lanes * 21.0 / chunk_s
-        stage_flops = [dit_forward_flops(cfg, S, q, kv) for q, kv in T2V_STAGE_SHAPES]
+        stage_flops = [dit_forward_flops(cfg, S, q, kv) for q, kv in stage_shapes]
         chunk_flops = 102.0 * sum(stage_flops)
         step_flops = (2.0 if pair is None else 1.0) * sum(stage_flops) / 4.0   # mean over the rotation, forwards per rank-step
         achieved_pf = step_flops / (elapsed / args.steps) / 1e15
@@ -236,8 +239,9 @@ def main():
             "metric": "video_latent_frames_per_sec", "value": value, "unit": "latent-frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"Wan2.1-T2V-{args.model} {args.res} chunk-AR denoise step (cond+uncond DiT forward, CFG, UniPC), "
-                                   f"rotating T2V stages s0..s3; one 21-latent-frame chunk per GPU = 204 step-equivalents",
+            "config": {"workload": f"Wan2.1-{args.mode.upper()}-{args.model} {args.res} chunk-AR denoise step (cond+uncond DiT forward, CFG, UniPC), "
+                                   f"rotating the four {args.mode.upper()} denoise stages {stage_shapes} (query, attended frames); one "
+                                   f"21-latent-frame chunk per GPU = 204 step-equivalents",
                        "frame_seqlen": S, "latent_hw": [lat_h, lat_w], "sampling_steps": 50, "guidance_scale": 5.0,
                        "parallelism": (f"chunk-per-rank x{world}" if pair is None else f"{n_lanes} chunk lanes x 2 (cond|uncond) CFG split, "
                                        "per-step 2-rank all-gather of flow predictions") +

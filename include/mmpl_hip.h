@@ -134,6 +134,22 @@ size_t mmpl_t5_workspace_bytes(const MmplT5* h);
 int mmpl_t5_encode(MmplT5* h, const int* ids, const int* mask, const int* bucket, void* out, void* workspace,
                    size_t workspace_bytes, mmpl_stream_t stream);
 
+/* ---- Wan-I2V image cross-attention (wan/modules/model.py:224-266 WanI2VCrossAttention, :469-481 MLPProj).
+ * mmpl_i2v_img_proj : clip_fea [n_tok=257, clip_dim=1280] -> context_img [n_tok, dim]; w = {proj.0.weight, proj.0.bias,
+ *                     proj.1.weight, proj.1.bias, proj.3.weight, proj.3.bias, proj.4.weight, proj.4.bias} (LayerNorm eps 1e-5,
+ *                     erf-GELU -- torch defaults).
+ * mmpl_i2v_img_kv   : k_img = norm_k_img(k_img(context_img)), v_img = v_img(context_img)  (once per prompt and layer).
+ * mmpl_i2v_cross_attn: out = o(attention(q, k_txt, v_txt) + attention(q, k_img, v_img)), q = norm_q(q(x)); x, out [Lq, dim]. */
+size_t mmpl_i2v_img_proj_workspace_bytes(int n_tok, int clip_dim, int dim);
+int mmpl_i2v_img_proj(const void* clip_fea, int n_tok, int clip_dim, int dim, const void* const* w, void* out, void* workspace,
+                      size_t workspace_bytes, mmpl_stream_t stream);
+int mmpl_i2v_img_kv(const void* ctx_img, int n_tok, int dim, const void* wk, const void* bk, const void* wv, const void* bv,
+                    const void* norm_k_img_w, float eps, void* k_out, void* v_out, mmpl_stream_t stream);
+size_t mmpl_i2v_cross_attn_workspace_bytes(int Lq, int dim);
+int mmpl_i2v_cross_attn(const void* x, int Lq, int dim, const void* wq, const void* bq, const void* norm_q_w, float eps,
+                        const void* k_txt, const void* v_txt, int n_txt, const void* k_img, const void* v_img, int n_img,
+                        const void* wo, const void* bo, void* out, void* workspace, size_t workspace_bytes, mmpl_stream_t stream);
+
 /* Optional per-kernel-class hipEvent timing (bench.py's live roofline numbers; off by default, not thread-safe).
  * kinds: 0 gemm, 1 self-attention, 2 cross-attention, 3 layernorm, 4 qk-norm/rope/kv-write, 5 elementwise, 6 cfg+unipc,
  * 7 vae.  mmpl_profile_read synchronises the device, sums the event pairs recorded since enable/last read. */

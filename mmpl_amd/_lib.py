@@ -15,6 +15,7 @@ SYMBOLS = [
     "mmpl_vae_num_weights", "mmpl_vae_weight_name", "mmpl_vae_create", "mmpl_vae_destroy", "mmpl_vae_bind_weights",
     "mmpl_vae_workspace_bytes", "mmpl_vae_decode", "mmpl_vae_encode",
     "mmpl_t5_num_weights", "mmpl_t5_create", "mmpl_t5_destroy", "mmpl_t5_bind_weights", "mmpl_t5_workspace_bytes", "mmpl_t5_encode",
+    "mmpl_i2v_img_proj_workspace_bytes", "mmpl_i2v_img_proj", "mmpl_i2v_img_kv", "mmpl_i2v_cross_attn_workspace_bytes", "mmpl_i2v_cross_attn",
     "mmpl_profile_enable", "mmpl_profile_read", "mmpl_last_error", "mmpl_version",
 ]
 
@@ -82,6 +83,14 @@ def load() -> C.CDLL:
     lib.mmpl_t5_workspace_bytes.argtypes = [vp]
     lib.mmpl_t5_workspace_bytes.restype = sz
     lib.mmpl_t5_encode.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp]
+    cf = C.c_float
+    lib.mmpl_i2v_img_proj_workspace_bytes.argtypes = [ci, ci, ci]
+    lib.mmpl_i2v_img_proj_workspace_bytes.restype = sz
+    lib.mmpl_i2v_img_proj.argtypes = [vp, ci, ci, ci, C.POINTER(vp), vp, vp, sz, vp]
+    lib.mmpl_i2v_img_kv.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, vp]
+    lib.mmpl_i2v_cross_attn_workspace_bytes.argtypes = [ci, ci]
+    lib.mmpl_i2v_cross_attn_workspace_bytes.restype = sz
+    lib.mmpl_i2v_cross_attn.argtypes = [vp, ci, ci, vp, vp, vp, cf, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, sz, vp]
     if hasattr(lib, "mmpl_vae_create"):
         _bind_vae(lib)
     _lib = lib

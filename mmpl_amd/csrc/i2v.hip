@@ -1,0 +1,113 @@
+// Wan-I2V image conditioning of the text cross-attention: MLPProj over the CLIP features
+// (MMPL_t2v/wan/modules/model.py:469-481) and WanI2VCrossAttention (model.py:224-266): the query attends separately to
+// the 257 projected image tokens and to the 512 text tokens, the two outputs are summed before the o-projection.
+// Host orchestration over the DiT kernels (gemm.hip, attention.hip, elementwise.hip) + two elementwise kernels; C ABI
+// mmpl_i2v_*.  The FPS wrapper of the reference never instantiates this module (its I2V mode conditions through the
+// VAE-encoded first frame only), so nothing in the denoising loop calls it; parity is against the module run standalone.
+#include <math.h>
+
+#include "../../include/mmpl_hip.h"
+#include "kernels.h"
+
+extern int mmpl_set_error(const char* where, const char* what);  // api.hip
+
+namespace {
+
+// torch.nn.GELU() (erf form) on a bf16 tensor: fp32 math, one rounding
+__global__ void gelu_erf_kernel(bf16_t* x, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = bf2f(x[i]);
+    x[i] = f2bf(0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)));
+  }
+}
+// a = bf16(a + b)   (x = x + img_x, model.py:262)
+__global__ void add_kernel(bf16_t* a, const bf16_t* b, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    a[i] = f2bf(bf2f(a[i]) + bf2f(b[i]));
+}
+
+hipError_t linear(const bf16_t* x, int K, const bf16_t* w, const bf16_t* b, bf16_t* y, int M, int N, hipStream_t s) {
+  GemmArgs g = {x, K, w, K, b, y, N, M, N, K, EPI_BIAS, nullptr, 0, nullptr, 0, 1, 1.0f, 0, 0, 0, 0, 0};
+  return mmpl_launch_gemm(g, s);
+}
+hipError_t attend(const bf16_t* q, bf16_t* o, const bf16_t* k, const bf16_t* v, int n_kv, int Lq, int dim, hipStream_t s) {
+  AttnArgs a = {};
+  a.q = q; a.ldq = dim; a.o = o; a.ldo = dim;
+  a.k_pages[0] = k; a.v_pages[0] = v; a.ldk = dim; a.ldv = dim;
+  a.n_pages = 1; a.page_rows = n_kv; a.Lq = Lq; a.H = dim / 128; a.scale = 1.0f / sqrtf(128.0f); a.cross = 1;
+  return mmpl_launch_attention(a, s);
+}
+int blocks_for(size_t n) { return (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256); }
+
+#define I2V_TRY(expr, where)                                                  \
+  do {                                                                        \
+    hipError_t e_ = (expr);                                                   \
+    if (e_ != hipSuccess) return mmpl_set_error(where, hipGetErrorString(e_)); \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+size_t mmpl_i2v_img_proj_workspace_bytes(int n_tok, int clip_dim, int dim) {
+  return ((size_t)2 * n_tok * clip_dim + (size_t)n_tok * dim) * sizeof(bf16_t) + 1024;
+}
+
+int mmpl_i2v_img_proj(const void* clip_fea, int n_tok, int clip_dim, int dim, const void* const* w, void* out, void* workspace,
+                      size_t workspace_bytes, mmpl_stream_t stream) {
+  if (!clip_fea || !w || !out || !workspace) return mmpl_set_error("mmpl_i2v_img_proj", "null argument");
+  if (n_tok < 1 || clip_dim % 128 || dim % 128 || clip_dim > 5120 || dim > 5120) return mmpl_set_error("mmpl_i2v_img_proj", "unsupported dims");
+  if (workspace_bytes < mmpl_i2v_img_proj_workspace_bytes(n_tok, clip_dim, dim)) return mmpl_set_error("mmpl_i2v_img_proj", "workspace too small");
+  for (int i = 0; i < 8; ++i)
+    if (!w[i]) return mmpl_set_error("mmpl_i2v_img_proj", "null weight pointer");
+  hipStream_t s = (hipStream_t)stream;
+  bf16_t* t0 = (bf16_t*)workspace;
+  bf16_t* t1 = t0 + (size_t)n_tok * clip_dim;
+  bf16_t* t2 = t1 + (size_t)n_tok * clip_dim;
+  const bf16_t* const* W = (const bf16_t* const*)w;   // proj.0.{weight,bias}, proj.1.{weight,bias}, proj.3.{weight,bias}, proj.4.{weight,bias}
+  LnArgs l0 = {(const bf16_t*)clip_fea, clip_dim, t0, clip_dim, n_tok, clip_dim, 1e-5f, nullptr, nullptr, 0, 1, W[0], W[1]};
+  I2V_TRY(mmpl_launch_layernorm(l0, s), "mmpl_i2v_img_proj: layernorm 0");
+  I2V_TRY(linear(t0, clip_dim, W[2], W[3], t1, n_tok, clip_dim, s), "mmpl_i2v_img_proj: fc1");
+  gelu_erf_kernel<<<blocks_for((size_t)n_tok * clip_dim), 256, 0, s>>>(t1, (size_t)n_tok * clip_dim);
+  I2V_TRY(linear(t1, clip_dim, W[4], W[5], t2, n_tok, dim, s), "mmpl_i2v_img_proj: fc2");
+  LnArgs l1 = {t2, dim, (bf16_t*)out, dim, n_tok, dim, 1e-5f, nullptr, nullptr, 0, 1, W[6], W[7]};
+  I2V_TRY(mmpl_launch_layernorm(l1, s), "mmpl_i2v_img_proj: layernorm 1");
+  I2V_TRY(hipGetLastError(), "mmpl_i2v_img_proj");
+  return 0;
+}
+
+int mmpl_i2v_img_kv(const void* ctx_img, int n_tok, int dim, const void* wk, const void* bk, const void* wv, const void* bv,
+                    const void* norm_k_img_w, float eps, void* k_out, void* v_out, mmpl_stream_t stream) {
+  if (!ctx_img || !wk || !bk || !wv || !bv || !norm_k_img_w || !k_out || !v_out) return mmpl_set_error("mmpl_i2v_img_kv", "null argument");
+  if (n_tok < 1 || dim % 128 || dim > 5120) return mmpl_set_error("mmpl_i2v_img_kv", "unsupported dims");
+  hipStream_t s = (hipStream_t)stream;
+  I2V_TRY(linear((const bf16_t*)ctx_img, dim, (const bf16_t*)wk, (const bf16_t*)bk, (bf16_t*)k_out, n_tok, dim, s), "mmpl_i2v_img_kv: k_img");
+  I2V_TRY(mmpl_launch_rmsnorm((bf16_t*)k_out, dim, (const bf16_t*)norm_k_img_w, n_tok, dim, eps, s), "mmpl_i2v_img_kv: norm_k_img");
+  I2V_TRY(linear((const bf16_t*)ctx_img, dim, (const bf16_t*)wv, (const bf16_t*)bv, (bf16_t*)v_out, n_tok, dim, s), "mmpl_i2v_img_kv: v_img");
+  return 0;
+}
+
+size_t mmpl_i2v_cross_attn_workspace_bytes(int Lq, int dim) { return (size_t)3 * Lq * dim * sizeof(bf16_t) + 1024; }
+
+int mmpl_i2v_cross_attn(const void* x, int Lq, int dim, const void* wq, const void* bq, const void* norm_q_w, float eps,
+                        const void* k_txt, const void* v_txt, int n_txt, const void* k_img, const void* v_img, int n_img,
+                        const void* wo, const void* bo, void* out, void* workspace, size_t workspace_bytes, mmpl_stream_t stream) {
+  if (!x || !wq || !bq || !norm_q_w || !k_txt || !v_txt || !k_img || !v_img || !wo || !bo || !out || !workspace)
+    return mmpl_set_error("mmpl_i2v_cross_attn", "null argument");
+  if (Lq < 1 || n_txt < 1 || n_img < 1 || dim % 128 || dim > 5120) return mmpl_set_error("mmpl_i2v_cross_attn", "unsupported dims");
+  if (workspace_bytes < mmpl_i2v_cross_attn_workspace_bytes(Lq, dim)) return mmpl_set_error("mmpl_i2v_cross_attn", "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  bf16_t* q = (bf16_t*)workspace;
+  bf16_t* at = q + (size_t)Lq * dim;
+  bf16_t* ai = at + (size_t)Lq * dim;
+  I2V_TRY(linear((const bf16_t*)x, dim, (const bf16_t*)wq, (const bf16_t*)bq, q, Lq, dim, s), "mmpl_i2v_cross_attn: q");
+  I2V_TRY(mmpl_launch_rmsnorm(q, dim, (const bf16_t*)norm_q_w, Lq, dim, eps, s), "mmpl_i2v_cross_attn: norm_q");
+  I2V_TRY(attend(q, ai, (const bf16_t*)k_img, (const bf16_t*)v_img, n_img, Lq, dim, s), "mmpl_i2v_cross_attn: image attention");
+  I2V_TRY(attend(q, at, (const bf16_t*)k_txt, (const bf16_t*)v_txt, n_txt, Lq, dim, s), "mmpl_i2v_cross_attn: text attention");
+  add_kernel<<<blocks_for((size_t)Lq * dim), 256, 0, s>>>(at, ai, (size_t)Lq * dim);
+  I2V_TRY(linear(at, dim, (const bf16_t*)wo, (const bf16_t*)bo, (bf16_t*)out, Lq, dim, s), "mmpl_i2v_cross_attn: o");
+  I2V_TRY(hipGetLastError(), "mmpl_i2v_cross_attn");
+  return 0;
+}
+
+}  // extern "C"

@@ -95,3 +95,5 @@ def dit_forward_flops(cfg: dict, frame_seqlen: int, n_q_frames: int, n_kv_frames
 
 # (query frames, attended frames) per T2V stage, first chunk
 T2V_STAGE_SHAPES = [(2, 2), (7, 9), (6, 13), (6, 21)]
+# I2V denoise stages s1..s4 (s0 = the image latent, refresh pass only; frames 19, 20 stay visible in s3): SURVEY.md App. A
+I2V_STAGE_SHAPES = [(1, 2), (7, 9), (6, 15), (6, 21)]

@@ -203,3 +203,28 @@ def t5_state_dict(cfg: dict, seed: int = 0, dtype=torch.bfloat16, device="cpu") 
         sd[p + "pos_embedding.embedding.weight"] = rn(nb, n, std=0.5)
     sd["norm.weight"] = (1 + 0.1 * torch.randn(d, generator=g, device=device)).to(dtype)
     return sd
+
+
+def i2v_cross_state_dict(dim: int, clip_dim: int = 1280, seed: int = 0, dtype=torch.bfloat16, device="cpu"):
+    """(WanI2VCrossAttention state_dict, MLPProj state_dict): keys / shapes of MMPL_t2v/wan/modules/model.py:224-236, 469-477."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+
+    def rn(*shape, std):
+        return (torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * std).to(dtype)
+    ca = OrderedDict()
+    for m in ("q", "k", "v", "o", "k_img", "v_img"):
+        ca[m + ".weight"] = rn(dim, dim, std=dim ** -0.5)
+        ca[m + ".bias"] = rn(dim, std=0.02)
+    for m in ("norm_q", "norm_k", "norm_k_img"):
+        ca[m + ".weight"] = (1 + rn(dim, std=0.1).float()).to(dtype)
+    mp = OrderedDict()
+    mp["proj.0.weight"] = (1 + rn(clip_dim, std=0.1).float()).to(dtype)
+    mp["proj.0.bias"] = rn(clip_dim, std=0.02)
+    mp["proj.1.weight"] = rn(clip_dim, clip_dim, std=clip_dim ** -0.5)
+    mp["proj.1.bias"] = rn(clip_dim, std=0.02)
+    mp["proj.3.weight"] = rn(dim, clip_dim, std=clip_dim ** -0.5)
+    mp["proj.3.bias"] = rn(dim, std=0.02)
+    mp["proj.4.weight"] = (1 + rn(dim, std=0.1).float()).to(dtype)
+    mp["proj.4.bias"] = rn(dim, std=0.02)
+    return ca, mp

@@ -122,3 +122,35 @@ def test_hipgraph_replay_matches_eager():
     for a, b in zip(outs["eager"][0], outs["graph"][0]):
         assert torch.equal(a, b)
     assert torch.equal(outs["eager"][1], outs["graph"][1])
+
+
+def test_forward_runtime_errors_raise():
+    """Error behaviour at the forward seam: bad slot tables / undersized workspace -> RuntimeError with the C-side message,
+    and the engine stays usable afterwards."""
+    from mmpl_amd.dit import DitEngine
+    from mmpl_amd.synthetic import WAN_CONFIGS, dit_state_dict, philox_normal
+    cfg = WAN_CONFIGS["tiny"]
+    eng = DitEngine(cfg, 16, 24, "cuda:0")
+    x = philox_normal([2, 16, 16, 24], 1).cuda()
+    t = torch.full([2], 500.0, device="cuda")
+    kc, vc = eng.new_kv_cache(15)
+    with pytest.raises(RuntimeError, match="weights not bound"):
+        eng.forward(x, t, [0, 1], [0, 1], [0, 1], kc, vc, kc[:, :512], vc[:, :512])
+    eng.load_state_dict(dit_state_dict(cfg, seed=2))
+    ck, cv = eng.precompute_context(philox_normal([512, cfg["text_dim"]], 3).cuda())
+    with pytest.raises(RuntimeError, match="visible slot out of range"):
+        eng.forward(x, t, [0, 1], [0, 1], [0, 99], kc, vc, ck, cv)
+    with pytest.raises(RuntimeError, match="write slot out of range"):
+        eng.forward(x, t, [0, 1], [0, 15], [0, 1], kc, vc, ck, cv)
+    with pytest.raises(RuntimeError, match="all >= 0 or all -1"):
+        eng.forward(x, t, [0, 1], [0, -1], [0, 1], kc, vc, ck, cv)
+    with pytest.raises(RuntimeError, match="too many"):
+        eng.forward(x, t, [0, 1], [0, 1], list(range(15)) * 2, kc, vc, ck, cv)
+    ws = eng.workspace(2)
+    eng._ws[2] = ws[:1024]
+    with pytest.raises(RuntimeError, match="workspace too small"):
+        eng.forward(x, t, [0, 1], [0, 1], [0, 1], kc, vc, ck, cv)
+    eng._ws[2] = ws
+    y = eng.forward(x, t, [0, 1], [0, 1], [0, 1], kc, vc, ck, cv)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all()

@@ -36,6 +36,8 @@ args = types.SimpleNamespace(model_kwargs={}, num_train_timestep=1000, timestep_
 pipe = CausalFPSInferencePipeline(args, dev, generator=gen, text_encoder=SyntheticTextEncoder(cfg["text_dim"], dev), vae=vae, save=None,
                                   geometry=geo)
 pipe.use_graphs = not a.no_graphs
+handoff = {}
+pipe.handoff_sink = lambda t: handoff.setdefault("t", t.clone())
 noise = torch.randn(1, 21, 16, geo.lat_h, geo.lat_w, device=dev).to(torch.bfloat16)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
@@ -45,12 +47,21 @@ t1 = time.perf_counter()
 video = pipe.vae.decode_to_pixel(lat)
 torch.cuda.synchronize()
 t2 = time.perf_counter()
+# consumer side of the inter-chunk hand-off (decode 4 latents -> 13 px frames -> encode 5 frames -> 2 latents)
+from mmpl_amd.handoff import handoff_to_initial_latent  # noqa: E402
+handoff_to_initial_latent(pipe.vae, handoff["t"])
+torch.cuda.synchronize()
+t3 = time.perf_counter()
+init = handoff_to_initial_latent(pipe.vae, handoff["t"])
+torch.cuda.synchronize()
+t4 = time.perf_counter()
 S = geo.frame_seqlen
 fl = [dit_forward_flops(cfg, S, q, kv) for q, kv in T2V_STAGE_SHAPES]
 n_fwd = [2 * a.steps + 2] * 3 + [2 * a.steps]          # the non-persisting stage skips its no-op refresh pair
 flops = sum(n * f for n, f in zip(n_fwd, fl))
 print(json.dumps({"model": a.model, "res": a.res, "sampling_steps": a.steps, "hipgraphs": pipe.use_graphs,
-                  "denoise_s": t1 - t0, "vae_decode_s": t2 - t1, "latent_frames_per_s_denoise": 21 / (t1 - t0),
+                  "denoise_s": t1 - t0, "vae_decode_s": t2 - t1, "handoff_transform_s": t4 - t3,
+                  "handoff_shape": list(handoff["t"].shape), "initial_latent_shape": list(init.shape), "latent_frames_per_s_denoise": 21 / (t1 - t0),
                   "latent_frames_per_s_end_to_end": 21 / (t2 - t0), "dit_forwards": sum(n_fwd), "algorithmic_pflop": flops / 1e15,
                   "achieved_pflops": flops / (t1 - t0) / 1e15, "finite": bool(torch.isfinite(video).all()),
                   "video_shape": list(video.shape)}))
