@@ -218,14 +218,14 @@ def encode(p: Dict[str, torch.Tensor], x: torch.Tensor, mean: torch.Tensor, inv_
 def decode_to_pixel(p, latent: torch.Tensor, mean, std) -> torch.Tensor:
     """wan_wrapper.py:90-113: latent [1, F, 16, h, w] -> [1, T, 3, H, W] float32 in [-1, 1]."""
     zs = latent.permute(0, 2, 1, 3, 4)
-    m = torch.tensor(mean, dtype=latent.dtype)
-    inv = 1.0 / torch.tensor(std, dtype=latent.dtype)
+    m = torch.tensor(mean, dtype=latent.dtype, device=latent.device)
+    inv = 1.0 / torch.tensor(std, dtype=latent.dtype, device=latent.device)
     out = decode(p, zs, m, inv).float().clamp_(-1, 1)
     return out.permute(0, 2, 1, 3, 4)
 
 
 def encode_to_latent(p, pixel: torch.Tensor, mean, std) -> torch.Tensor:
     """wan_wrapper.py:74-88: pixel [1, 3, T, H, W] -> [1, F, 16, h, w] float32."""
-    m = torch.tensor(mean, dtype=pixel.dtype)
-    inv = 1.0 / torch.tensor(std, dtype=pixel.dtype)
+    m = torch.tensor(mean, dtype=pixel.dtype, device=pixel.device)
+    inv = 1.0 / torch.tensor(std, dtype=pixel.dtype, device=pixel.device)
     return encode(p, pixel, m, inv).float().permute(0, 2, 1, 3, 4)

@@ -5,11 +5,15 @@ the SAME oracle code (oracle/wan_dit_ref.py) evaluated by PyTorch on the device 
 groups so the score matrix stays bounded) -- an implementation that shares nothing with libmmpl_hip.so.  The CPU
 oracle itself is pinned to the reference in tests/test_oracle_golden.py; its device evaluation is tied back to the
 CPU one on the small case below.  Stated tolerance: rel-L2 <= 2e-2 per forward."""
-import pytest
-import torch
-import torch.nn.functional as F
+import os
 
-from tests.util import rel_l2
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")     # the checker's torch convolutions: skip MIOpen's exhaustive search
+
+import pytest  # noqa: E402
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from tests.util import rel_l2  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-2
@@ -98,3 +102,55 @@ def test_full_size_forward_all_stage_patterns(cfg_name, lat):
     errs = _stages(cfg_name, lat)
     print(f"{cfg_name} {lat}: rel_l2(HIP, oracle on device) per stage = " + ", ".join(f"{e:.3e}" for e in errs))
     assert max(errs) < TOL
+
+
+def test_vae_720p_decode_encode_vs_device_evaluated_oracle():
+    """The Wan 3D-VAE at the 720p geometry (latents 90x160 -> 720x1280 px): decode of 2 latent frames (5 px frames) and
+    encode of 5 px frames (2 latents), HIP vs oracle/vae_ref.py evaluated by PyTorch on the device (the CPU oracle
+    needs ~0.1 PFLOP here).  Tolerance as in tests/test_vae_gpu.py: rel-L2 <= 3e-2."""
+    from mmpl_amd.synthetic import vae_state_dict
+    from mmpl_amd.vae import VaeEngine
+    from oracle import vae_ref
+    from tests.test_vae_gpu import MEAN, STD
+    dev = "cuda:0"
+    sd = vae_state_dict(seed=3)
+    eng = VaeEngine(90, 160, dev)
+    eng.load_state_dict(sd)
+    sdd = {k: v.to(dev) for k, v in sd.items()}
+    g = torch.Generator(device=dev).manual_seed(5)
+    z = torch.randn(2, 16, 90, 160, generator=g, device=dev).bfloat16()
+    out = eng.decode(z, MEAN, STD)                                                  # [5, 3, 720, 1280]
+    ref = vae_ref.decode_to_pixel(sdd, z.unsqueeze(0), MEAN, STD)[0]
+    torch.cuda.synchronize()
+    e_dec = rel_l2(out, ref)
+    px = (torch.rand(3, 5, 720, 1280, generator=g, device=dev) * 2 - 1).bfloat16()
+    lat = eng.encode(px, MEAN, STD)                                                 # [2, 16, 90, 160]
+    ref_lat = vae_ref.encode_to_latent(sdd, px.unsqueeze(0), MEAN, STD)[0]
+    torch.cuda.synchronize()
+    e_enc = rel_l2(lat, ref_lat)
+    print(f"VAE 720p: rel_l2(HIP, oracle on device) decode = {e_dec:.3e}, encode = {e_enc:.3e}")
+    assert out.shape == (5, 3, 720, 1280) and lat.shape == (2, 16, 90, 160)
+    assert e_dec < 3e-2 and e_enc < 3e-2
+
+
+def test_t5_production_dims_two_layers_vs_cpu_oracle():
+    """umT5-xxl dims (dim 4096, 64 heads, ffn 10240, text_len 512), two layers, against the pinned CPU oracle."""
+    from mmpl_amd.synthetic import t5_state_dict
+    from mmpl_amd.t5 import T5Engine
+    from oracle import t5_ref
+    cfg = dict(vocab=2048, dim=4096, dim_attn=4096, dim_ffn=10240, num_heads=64, num_layers=2, num_buckets=32)
+    sd = t5_state_dict(cfg, seed=13)
+    L = 512
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(2, cfg["vocab"], (1, L), generator=g)
+    mask = torch.zeros(1, L, dtype=torch.long)
+    mask[0, :91] = 1
+    ids[0, 91:] = 0
+    want = t5_ref.text_encoder_forward(sd, ids, mask, cfg["num_heads"], cfg["num_buckets"], cfg["num_layers"])
+    eng = T5Engine(cfg, text_len=L, device="cuda:0")
+    eng.load_state_dict(sd)
+    out = eng.encode(ids, mask)
+    torch.cuda.synchronize()
+    e = rel_l2(out[0, :91], want[0, :91])
+    print(f"umT5 xxl dims, 2 layers: rel_l2(HIP, CPU oracle) = {e:.3e}")
+    assert e < 2e-2 and out[0, 91:].abs().sum().item() == 0
