@@ -36,12 +36,6 @@ def load_config(path):
     return types.SimpleNamespace(**cfg)
 
 
-def read_prompts(path):
-    """utils/dataset.py:12-34 (TextDataset): one prompt per line."""
-    with open(path, encoding="utf-8") as f:
-        return [ln.strip() for ln in f if ln.strip()]
-
-
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--config_path", type=str)
@@ -104,7 +98,12 @@ def main(argv=None):
         sd = torch.load(args.checkpoint_path, map_location="cpu")
         pipe.generator_cond.load_state_dict(sd["generator" if not args.use_ema else "generator_ema"])
 
-    prompts = read_prompts(args.data_path) if args.data_path else ["a cat running on the grass"]
+    if args.data_path:
+        from .utils.dataset import TextDataset
+        ds = TextDataset(args.data_path)
+        prompts = [ds[i]["prompts"] for i in range(len(ds))]
+    else:
+        prompts = ["a cat running on the grass"]
     os.makedirs(args.output_folder, exist_ok=True)
     shape = [1, args.num_output_frames, 16, geo.lat_h, geo.lat_w]
     for idx, prompt in enumerate(prompts):
@@ -140,7 +139,9 @@ def main(argv=None):
             out = (full[0].permute(0, 2, 3, 1) * 255.0).clamp(0, 255).to(torch.uint8)
             path = os.path.join(args.output_folder, f"{idx}-0.pt")
             torch.save(out, path)
-            print(f"[mmpl_amd.cli] prompt {idx}: {tuple(out.shape)} frames @16 fps -> {path}")
+            from .utils.video_io import write_video
+            vpath = write_video(os.path.join(args.output_folder, f"{idx}-0.mp4"), out, fps=16)    # Wan_fps_inference_1gpu.py:225
+            print(f"[mmpl_amd.cli] prompt {idx}: {tuple(out.shape)} frames @16 fps -> {vpath} (+ {path})")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
