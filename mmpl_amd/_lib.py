@@ -50,6 +50,10 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} not found: the MI355X HIP extension is not built. Run `python -m mmpl_amd.build` "
             "(or __graft_entry__.build()). mmpl_amd has no CPU/PyTorch fallback by design.")
+    # torch first: it ships its own libamdhip64, and device memory / streams are shared with it.  If this library were
+    # dlopen'ed before torch, the system HIP runtime would be bound instead and every hipMalloc here would fail once torch
+    # initialises the device through the other copy (seen as "hipMalloc ... failed" in build() -> smoke() in one process).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, ci, cf, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
     lib.mmpl_last_error.restype = C.c_char_p

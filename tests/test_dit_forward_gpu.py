@@ -154,3 +154,16 @@ def test_forward_runtime_errors_raise():
     y = eng.forward(x, t, [0, 1], [0, 1], [0, 1], kc, vc, ck, cv)
     torch.cuda.synchronize()
     assert torch.isfinite(y.float()).all()
+
+
+def test_build_then_smoke_in_one_process():
+    """__graft_entry__.build() followed by smoke() in ONE fresh process (the library is dlopen'ed before anything touched
+    the device): regression test for the HIP-runtime load order (mmpl_amd/_lib.py imports torch before dlopen)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=root, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "[smoke]" in r.stdout
