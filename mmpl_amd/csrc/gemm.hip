@@ -300,98 +300,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   gemm_epilogue<EPI>(g, acc, m0 + 64 * wm, n0 + 64 * wn, frow, fchunk);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// v3: 256x256x32 tile, 8 waves (2x4), wave tile 128x64 (8x4 fragments, 128 accumulator VGPRs): 25 % fewer LDS
-// fragment reads per MFMA than a 64x64 wave tile, which is what bounds v2 (LDS ~70 % busy).  Same DMA ring as v2 but
-// BK = 32 so three 32 KiB stages fit: 4 LDS-DMA instructions per wave per tile -> s_waitcnt vmcnt(4).
-constexpr int BM3 = 256, BN3 = 256, BK3 = 32;
-constexpr int A3_BYTES = BM3 * BK3 * 2, STAGE3 = 2 * A3_BYTES, NSTAGE3 = 3;
-MMPL_DEV int swz32(int r, int c) { return r * 64 + ((c ^ ((0 - (r >> 2)) & 3)) << 4); }
-
-template <int EPI>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_v3_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tiles_m = (g.M + BM3 - 1) / BM3, tiles_n = (g.N + BN3 - 1) / BN3;
-  const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int GROUP = g.group;
-  const int per_group = GROUP * tiles_n;
-  const int gid = bid / per_group;
-  const int first_m = gid * GROUP;
-  const int gsz = min(tiles_m - first_m, GROUP);
-  const int tm = first_m + (bid % per_group) % gsz;
-  const int tn = (bid % per_group) / gsz;
-  const int m0 = tm * BM3, n0 = tn * BN3;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;   // 2 x 4 waves, 128 x 64 each
-
-  const bf16_t* a_src[2];
-  const bf16_t* w_src[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int p = (j * 8 + wave) * 64 + lane, row = p >> 2, c = (p & 3) ^ ((0 - (row >> 2)) & 3);
-    a_src[j] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + c * 8;
-    w_src[j] = g.W + (size_t)min(n0 + row, g.N - 1) * g.ldw + c * 8;
-  }
-  auto issue = [&](int t) {
-    char* st = smem + (t % NSTAGE3) * STAGE3;
-    const int koff = t * BK3;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) glds16(a_src[j] + koff, st + (j * 8 + wave) * 1024);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) glds16(w_src[j] + koff, st + A3_BYTES + (j * 8 + wave) * 1024);
-  };
-
-  f32x4 acc[2][4][4];
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int frow = lane & 15, fchunk = lane >> 4;
-  int a_off[8], w_off[4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) a_off[i] = swz32(128 * wm + 16 * i + frow, fchunk);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) w_off[i] = A3_BYTES + swz32(64 * wn + 16 * i + frow, fchunk);
-
-  const int nt = g.K / BK3;
-  issue(0);
-  if (nt > 1) {
-    issue(1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-
-  for (int t = 0; t < nt; ++t) {
-    if (t + 2 < nt) issue(t + 2);
-    const char* st = smem + (t % NSTAGE3) * STAGE3;
-    bf16x8 af[8], wf[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + w_off[i]);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + a_off[i]);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i >> 2][i & 3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i >> 2][i & 3][j], 0, 0, 0);
-    if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-  gemm_epilogue<EPI>(g, acc[0], m0 + 128 * wm, n0 + 64 * wn, frow, fchunk);
-  gemm_epilogue<EPI>(g, acc[1], m0 + 128 * wm + 64, n0 + 64 * wn, frow, fchunk);
-}
+// (v3 -- 256x256x32 tile, 3-stage DMA ring, 990 TFLOP/s -- was removed once v4 / v6 superseded it; the tile constants stay)
+constexpr int BM3 = 256, BN3 = 256;
 
 // ---------------------------------------------------------------------------------------------------------------
 // v4 (MMPL_GEMM_V4=1; the lock-step predecessor of v6): v3 geometry with BK = 64 and a 2-stage ring (2 x 64 KiB): half as many barriers per MFMA, the DMA of
@@ -655,27 +565,8 @@ hipError_t launch_v2(const GemmArgs& g, hipStream_t s) {
 }
 
 template <int EPI>
-hipError_t launch_v3(const GemmArgs& g, hipStream_t s) {
-  static bool attr_set = false;
-  constexpr int smem = NSTAGE3 * STAGE3;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_v3_kernel<EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  const int tiles = ((g.M + BM3 - 1) / BM3) * ((g.N + BN3 - 1) / BN3);
-  static const int group = getenv("MMPL_GEMM_GROUP") ? atoi(getenv("MMPL_GEMM_GROUP")) : 4;
-  GemmArgs g2 = g;
-  g2.group = group;
-  hipLaunchKernelGGL(gemm_bf16_v3_kernel<EPI>, dim3(tiles), dim3(512), smem, s, g2);
-  return hipGetLastError();
-}
-
-template <int EPI>
 hipError_t launch(const GemmArgs& g, hipStream_t s) {
   const bool big = g.batch <= 1 && g.M >= 1024 && g.N >= 256 && g.K >= 128 && !getenv("MMPL_GEMM_V1") && !getenv("MMPL_GEMM_V2");
-  if (big && getenv("MMPL_GEMM_V3")) return launch_v3<EPI>(g, s);
   if (big && !getenv("MMPL_GEMM_V4") && (long long)g.M * g.lda < (1ll << 31) && (long long)g.N * g.ldw < (1ll << 31)) return launch_v6<EPI>(g, s);
   if (big) return launch_v4<EPI>(g, s);
   if (g.batch <= 1 && g.M >= 1024 && g.N >= 128 && g.K >= 128 && !getenv("MMPL_GEMM_V1")) return launch_v2<EPI>(g, s);
