@@ -118,14 +118,16 @@ class DitEngine:
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, t: torch.Tensor, frame_ids: Sequence[int], write_slots: Sequence[int],
                 visible_slots: Sequence[int], k_cache: torch.Tensor, v_cache: torch.Tensor, cross_k: torch.Tensor,
-                cross_v: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """x: [nF, 16, lat_h, lat_w] bf16; t: [nF] float32 (device).  Returns flow prediction, same shape as x."""
+                cross_v: torch.Tensor, out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x: [nF, 16, lat_h, lat_w] bf16; t: [nF] float32 (device).  Returns flow prediction, same shape as x.
+        `workspace`: a private scratch buffer (>= workspace_bytes(nF)) for a forward that runs concurrently with another
+        one on a different stream (cond / uncond); default: the engine's own."""
         nF = x.shape[0]
         assert x.is_contiguous() and x.dtype == torch.bfloat16 and x.shape[1:] == (16, self.lat_h, self.lat_w)
         assert t.dtype == torch.float32 and t.numel() == nF and t.is_cuda
         if out is None:
             out = torch.empty_like(x)
-        ws = self.workspace(nF)
+        ws = self.workspace(nF) if workspace is None else workspace
         n_slots = k_cache.shape[1] // self.S
         ia = lambda v: (C.c_int * len(v))(*[int(i) for i in v])
         _lib.check(self._lib.mmpl_dit_forward(
