@@ -6,11 +6,12 @@
 
 One *step* = one denoise step of the reference's hot loop (MMPL_t2v/pipeline/casual_fps_inference.py:338-374):
 cond DiT forward + uncond DiT forward (separate KV caches) + CFG combine + UniPC update, all HIP.  Steps rotate
-through the four T2V stage shapes s0..s3 (2/7/6/6 query frames attending 2/9/13/21 frames), so K steps (K % 4 == 0)
-sample every stage equally.  A first chunk is 4 stages x (50 denoise steps + 1 cache-refresh pair) = 204
+through the four T2V stage shapes s0..s3 (2/7/6/6 query frames attending 2/9/13/21 frames), so K steps (any K; each step is also timed by a HIP event pair and the chunk time is assembled per stage)
+sample the stages in turn.  A first chunk is 4 stages x (50 denoise steps + 1 cache-refresh pair) = 204
 step-equivalents (408 forwards), hence
 
-    latent-frames/s = 21 / (204 * mean step time)          (whole-job: summed over ranks, each rank = one chunk)
+    latent-frames/s = 21 / (51 * sum over the 4 stages of that stage's mean step time)
+                                                           (whole-job: summed over ranks, each rank = one chunk)
 
 Inputs (weights, KV caches, context, latents) are synthetic and resident in HBM before the timed region.
 Extra JSON objects: `roofline` for the dominant kernel (self-attention; MFMA bound) from hipEvent pairs recorded
@@ -92,7 +93,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    assert args.steps % 4 == 0 and args.steps > 0, "--steps must be a positive multiple of 4 (one per T2V stage shape)"
+    assert args.steps > 0 and args.warmup >= 0
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     pair, lanes, lane, n_lanes = None, None, rank, world
@@ -200,12 +201,18 @@ def main():
     barrier()
     if not args.no_profile:
         lib.mmpl_profile_enable(1)
+    # the K timed steps keep rotating through the four stage shapes; every step is also bracketed by a HIP event pair so
+    # that the chunk time can be assembled per stage (exact for any K, not only multiples of 4)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        one_step(i)
+        ev[i][0].record()
+        one_step(args.warmup + i)
+        ev[i][1].record()
     torch.cuda.current_stream().wait_stream(side)
     barrier()
     elapsed = time.perf_counter() - t0
+    step_s = [e0.elapsed_time(e1) * 1e-3 for e0, e1 in ev]
     prof = None
     if not args.no_profile:
         n = len(KIND_NAMES)
@@ -233,19 +240,23 @@ def main():
             vae_s = time.perf_counter() - tv
         except Exception as e:
             vae_s = f"failed: {e!r}"
+    # per-stage mean step time; a stage the K steps did not reach is priced at the measured FLOP rate of the others
+    stage_flops = [dit_forward_flops(cfg, S, q, kv) for q, kv in stage_shapes]
+    per_stage = [[step_s[i] for i in range(args.steps) if (args.warmup + i) % 4 == k] for k in range(4)]
+    seen = [k for k in range(4) if per_stage[k]]
+    rate = sum(stage_flops[k] for k in seen) / sum(sum(per_stage[k]) / len(per_stage[k]) for k in seen)
+    stage_s = [sum(per_stage[k]) / len(per_stage[k]) if per_stage[k] else stage_flops[k] / rate for k in range(4)]
+    chunk_s = 51.0 * sum(stage_s)                  # 4 stages x (50 denoise steps + 1 refresh pair) = 204 step-equivalents
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed, chunk_s], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
+        elapsed, chunk_s = tt[0].item(), tt[1].item()
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        chunk_s = 204.0 * elapsed / args.steps
         value = n_lanes * 21.0 / chunk_s
-        stage_flops = [dit_forward_flops(cfg, S, q, kv) for q, kv in stage_shapes]
         chunk_flops = 102.0 * sum(stage_flops)
-        step_flops = (2.0 if pair is None else 1.0) * sum(stage_flops) / 4.0   # mean over the rotation, forwards per rank-step
-        achieved_pf = step_flops / (elapsed / args.steps) / 1e15
+        achieved_pf = (2.0 if pair is None else 1.0) * 51.0 * sum(stage_flops) / chunk_s / 1e15    # forwards per rank-step
         res = {
             "metric": "video_latent_frames_per_sec", "value": value, "unit": "latent-frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -258,6 +269,7 @@ def main():
                                        "per-step 2-rank all-gather of flow predictions") +
                                       (" + RCCL p2p anchor hand-off lane->lane+1" if world > 1 else "")},
             "sec_per_denoise_step": elapsed / args.steps,
+            "sec_per_denoise_step_by_stage": stage_s,
             "sec_per_chunk_extrapolated": chunk_s,
             "achieved_pflops_per_gpu": achieved_pf,
             "mfma_frac_whole_step": achieved_pf * 1e3 / MFMA_PEAK_TFLOPS,
