@@ -69,6 +69,13 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int n_fra
 int mmpl_attn_fwd(const void* q, int ldq, void* o, int ldo, const void* const* k_pages, const void* const* v_pages,
                   int ldk, int ldv, int n_pages, int page_rows, int Lq, int num_heads, float softmax_scale,
                   mmpl_stream_t stream);
+/* Same, with scratch for the split-KV tail round (mmpl_attn_workspace_bytes() is always enough; NULL = mmpl_attn_fwd):
+ * when the query blocks do not fill the last round of one-block-per-CU evenly, the leftover blocks are run as 2..4 blocks
+ * over disjoint KV ranges plus a merge, which shortens the launch by up to one block time. */
+size_t mmpl_attn_workspace_bytes(void);
+int mmpl_attn_fwd_ws(const void* q, int ldq, void* o, int ldo, const void* const* k_pages, const void* const* v_pages,
+                     int ldk, int ldv, int n_pages, int page_rows, int Lq, int num_heads, float softmax_scale,
+                     void* workspace, size_t workspace_bytes, mmpl_stream_t stream);
 
 /* nn.Linear (+ fused epilogue). epi: 0 bias, 1 bias+GELU(tanh), 2 bias+SiLU, 3 x + (y*gate[frame]) , 4 x + y */
 int mmpl_gemm(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N, int K,

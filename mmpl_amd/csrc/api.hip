@@ -333,6 +333,8 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
           a.v_pages[np] = w.vsc + (size_t)i * S * d;
         }
       a.n_pages = np;
+      a.split_ws = (float*)w.xn;                    // norm1's output is dead once the QKV GEMM has consumed it
+      a.split_ws_bytes = (size_t)Lq * d * sizeof(bf16_t);
       ProfScope ps(K_ATTN_SELF, 4.0 * Lq * (double)np * S * d, s);
       HIP_TRY(mmpl_launch_attention(a, s), "self attention");
     }
@@ -379,16 +381,26 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
 }
 
 // ------------------------------------------------------------------------------------------------ single kernels
-int mmpl_attn_fwd(const void* q, int ldq, void* o, int ldo, const void* const* k_pages, const void* const* v_pages,
-                  int ldk, int ldv, int n_pages, int page_rows, int Lq, int num_heads, float softmax_scale,
-                  mmpl_stream_t stream) {
+size_t mmpl_attn_workspace_bytes(void) { return mmpl_attention_split_ws_bytes(); }
+
+int mmpl_attn_fwd_ws(const void* q, int ldq, void* o, int ldo, const void* const* k_pages, const void* const* v_pages,
+                     int ldk, int ldv, int n_pages, int page_rows, int Lq, int num_heads, float softmax_scale,
+                     void* workspace, size_t workspace_bytes, mmpl_stream_t stream) {
   if (n_pages < 1 || n_pages > MMPL_MAX_PAGES) return fail("mmpl_attn_fwd", "n_pages out of range");
   AttnArgs a = {};
   a.q = (const bf16_t*)q; a.ldq = ldq; a.o = (bf16_t*)o; a.ldo = ldo; a.ldk = ldk; a.ldv = ldv; a.n_pages = n_pages;
   a.page_rows = page_rows; a.Lq = Lq; a.H = num_heads; a.scale = softmax_scale;
+  a.split_ws = (float*)workspace; a.split_ws_bytes = workspace ? workspace_bytes : 0;
   for (int i = 0; i < n_pages; ++i) { a.k_pages[i] = (const bf16_t*)k_pages[i]; a.v_pages[i] = (const bf16_t*)v_pages[i]; }
   HIP_TRY(mmpl_launch_attention(a, (hipStream_t)stream), "mmpl_attn_fwd");
   return 0;
+}
+
+int mmpl_attn_fwd(const void* q, int ldq, void* o, int ldo, const void* const* k_pages, const void* const* v_pages,
+                  int ldk, int ldv, int n_pages, int page_rows, int Lq, int num_heads, float softmax_scale,
+                  mmpl_stream_t stream) {
+  return mmpl_attn_fwd_ws(q, ldq, o, ldo, k_pages, v_pages, ldk, ldv, n_pages, page_rows, Lq, num_heads, softmax_scale, nullptr, 0,
+                          stream);
 }
 
 int mmpl_gemm(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N, int K,

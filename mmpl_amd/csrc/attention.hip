@@ -277,7 +277,10 @@ MMPL_DEV void glds16(const void* base, uint32_t voff, char* lds) {   // base: wa
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(dst) : "memory");
 }
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_pp_kernel(AttnArgs a) {
+// SPLIT (the tail round, see mmpl_launch_attention): the block handles KV tiles [part*T/sp, (part+1)*T/sp) of query block
+// `local_base + idx / sp` and writes an un-normalised fp32 partial (O, m, l) for attn_merge_kernel.
+template <bool SPLIT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_pp_kernel(AttnArgs a, int local_base, int sp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -285,8 +288,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int hi = lane >> 5, l31 = lane & 31;
 
   const int n_qb = (a.Lq + QB - 1) / QB;
-  int head, qb;
-  if ((a.H & 7) == 0) {
+  int head, qb, part = 0, tail_idx = 0;
+  if (SPLIT) {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    part = idx % sp;
+    tail_idx = idx / sp;
+    const int local = local_base + tail_idx;
+    head = xcd + 8 * (local / n_qb);
+    qb = local % n_qb;
+    tail_idx = xcd * (gridDim.x / (8 * sp)) + tail_idx;
+  } else if ((a.H & 7) == 0) {
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
     head = xcd + 8 * (local / n_qb);
     qb = local % n_qb;
@@ -308,7 +319,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 
   const int tiles_pp = (a.page_rows + KVB - 1) / KVB;
-  const int T = a.n_pages * tiles_pp;
+  const int T_all = a.n_pages * tiles_pp;
+  const int t_first = SPLIT ? (int)((long long)part * T_all / sp) : 0;
+  const int T = SPLIT ? (int)((long long)(part + 1) * T_all / sp) - t_first : T_all;     // tiles of THIS block
   char* const kring = smem;
   char* const vring = smem + PP_RK * PP_TILE;
 
@@ -323,12 +336,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     dko[h] = (uint32_t)(row * a.ldk + ((dchunk ^ (row & 15)) << 3)) * 2u;
     dvo[h] = (uint32_t)(row * a.ldv + ((dchunk ^ ((row & 3) << 2)) << 3)) * 2u;
   }
-  int ipg = 0, irow0 = 0, it = 0;          // next tile to issue
+  int ipg = t_first / tiles_pp, irow0 = (t_first % tiles_pp) * KVB, it = 0;          // next tile to issue
   // wave-uniform source pointers of that tile (first row, this head).  They are advanced / re-read from the page table
   // in issue_advance() and PINNED there: a scalar load first used inside the matrix segment would put an
   // s_waitcnt lgkmcnt(0) in front of the DMA op, draining the wave's whole LDS fragment prefetch window each time
-  const bf16_t* kcur = a.k_pages[0] + head * 128;
-  const bf16_t* vcur = a.v_pages[0] + head * 128;
+  const bf16_t* kcur = a.k_pages[ipg] + (size_t)irow0 * a.ldk + head * 128;
+  const bf16_t* vcur = a.v_pages[ipg] + (size_t)irow0 * a.ldv + head * 128;
   asm volatile("" : "+s"(kcur), "+s"(vcur));
   // piece k of the tile being issued: 0 = K rows 0..31 share, 1 = V, 2 = K rows 32..63 share, 3 = V
   auto issue_piece = [&](int k) {
@@ -393,7 +406,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   f32x16 s0, s1;
   bf16x8 pb[2][2];
-  int crow0 = 0;                                    // first kv row (within its page) of compute tile j
+  int crow0 = (t_first % tiles_pp) * KVB;           // first kv row (within its page) of compute tile j
   constexpr int PD = 6;                             // LDS fragments requested ahead of the MFMA that consumes them
 
   // ---- M_j: 16 PV MFMAs of tile j-1, then 16 QK^T MFMAs of tile j (two accumulator chains, alternating).  The LDS
@@ -518,6 +531,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (grp == 0) __builtin_amdgcn_s_barrier();
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (SPLIT) {
+    // partial of this KV range: O (fp32, relative to m_run), then m, l per row -- [tail block][part][256 rows][128 + 2]
+    float* pbase = a.split_ws + ((size_t)tail_idx * sp + part) * (QB * 130);
+    const int rr = wave * QW + l31;
+    float* op = pbase + (size_t)rr * 128 + 4 * hi;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(op + 32 * nb + 8 * g) = f32x4{o[nb][4 * g], o[nb][4 * g + 1], o[nb][4 * g + 2], o[nb][4 * g + 3]};
+    if (hi == 0) {
+      pbase[QB * 128 + rr] = m_run;
+      pbase[QB * 129 + rr] = l_tot;
+    }
+    return;
+  }
   const float inv = 1.0f / l_tot;
   const int q_out = qb * QB + wave * QW + l31;
   if (q_out < a.Lq) {
@@ -534,7 +563,47 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// Combine the `sp` KV-range partials of each tail query block: O = sum_p w_p O_p / sum_p w_p l_p, w_p = 2^((m_p - m) c).
+__global__ __launch_bounds__(256) void attn_merge_kernel(AttnArgs a, int local_base, int sp, int tb) {
+  __shared__ float wgt[QB][4];
+  const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+  const int n_qb = (a.Lq + QB - 1) / QB;
+  const int local = local_base + k, head = xcd + 8 * (local / n_qb), qb = local % n_qb;
+  const float* base = a.split_ws + (size_t)(xcd * tb + k) * sp * (QB * 130);
+  const float c = a.scale * 1.4426950408889634f;
+  {
+    const int r = threadIdx.x;
+    float m = -INFINITY;
+    for (int p = 0; p < sp; ++p) m = fmaxf(m, base[(size_t)p * (QB * 130) + QB * 128 + r]);
+    float l = 0.f, w[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < sp; ++p) {
+      w[p] = __builtin_amdgcn_exp2f((base[(size_t)p * (QB * 130) + QB * 128 + r] - m) * c);
+      l += w[p] * base[(size_t)p * (QB * 130) + QB * 129 + r];
+    }
+    const float inv = 1.0f / l;
+    for (int p = 0; p < 4; ++p) wgt[r][p] = w[p] * inv;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < QB * 32; i += 256) {          // 16-byte chunks, coalesced
+    const int r = i >> 5, ch = i & 31, q_out = qb * QB + r;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < sp; ++p) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)p * (QB * 130) + (size_t)r * 128 + ch * 4);
+      const float w = wgt[r][p];
+      acc[0] += w * v[0]; acc[1] += w * v[1]; acc[2] += w * v[2]; acc[3] += w * v[3];
+    }
+    if (q_out < a.Lq) {
+      uint2 o2;
+      o2.x = pack2bf(acc[0], acc[1]);
+      o2.y = pack2bf(acc[2], acc[3]);
+      *reinterpret_cast<uint2*>(a.o + (size_t)q_out * a.ldo + head * 128 + ch * 4) = o2;
+    }
+  }
+}
+
 }  // namespace
+
+size_t mmpl_attention_split_ws_bytes() { return (size_t)256 * QB * 130 * sizeof(float); }   // <= one block per CU in the tail round
 
 hipError_t mmpl_launch_attention(const AttnArgs& a, hipStream_t s) {
   if (a.Lq <= 0) return hipSuccess;
@@ -548,7 +617,9 @@ hipError_t mmpl_launch_attention(const AttnArgs& a, hipStream_t s) {
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PP_SMEM);
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_SMEM);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_SMEM);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
@@ -558,6 +629,33 @@ hipError_t mmpl_launch_attention(const AttnArgs& a, hipStream_t s) {
   static const bool force_v1 = getenv("MMPL_ATTN_V1") && atoi(getenv("MMPL_ATTN_V1"));
   if (a.cross) hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(n_qb * a.H), dim3(512), SMEM, s, a);
   else if (force_v1) hipLaunchKernelGGL(attn_fwd_kernel<0>, dim3(n_qb * a.H), dim3(512), SMEM, s, a);
-  else hipLaunchKernelGGL(attn_pp_kernel, dim3(n_qb * a.H), dim3(512), PP_SMEM, s, a);
+  else {
+    // Tail round: with one block per CU and b = n_qb*H/8 query blocks per XCD (32 CUs), the last b mod 32 blocks of every
+    // XCD would run alone for a whole block time.  They are launched instead as `sp` blocks each over 1/sp of the KV tiles
+    // (fp32 partials in split_ws) followed by a small merge kernel, so the tail round lasts ~1/sp block times.
+    static int per_xcd = 0;
+    static const bool no_split = getenv("MMPL_ATTN_NOSPLIT") && atoi(getenv("MMPL_ATTN_NOSPLIT"));
+    if (!per_xcd) {
+      hipDeviceProp_t prop;
+      int dev = 0;
+      per_xcd = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount / 8 : 32;
+      if (per_xcd < 1) per_xcd = 32;
+    }
+    const int tiles = a.n_pages * ((a.page_rows + KVB - 1) / KVB);
+    int sp = 1, tb = 0, b = 0;
+    if (!no_split && a.split_ws && (a.H & 7) == 0) {
+      b = n_qb * (a.H / 8);
+      tb = b % per_xcd;
+      if (b > per_xcd && tb > 0 && per_xcd / tb >= 2) sp = per_xcd / tb > 4 ? 4 : per_xcd / tb;
+      if (tiles / sp < 8 || (size_t)8 * tb * sp * QB * 130 * sizeof(float) > a.split_ws_bytes) sp = 1;
+    }
+    if (sp == 1) {
+      hipLaunchKernelGGL(attn_pp_kernel<false>, dim3(n_qb * a.H), dim3(512), PP_SMEM, s, a, 0, 1);
+    } else {
+      hipLaunchKernelGGL(attn_pp_kernel<false>, dim3(8 * (b - tb)), dim3(512), PP_SMEM, s, a, 0, 1);
+      hipLaunchKernelGGL(attn_pp_kernel<true>, dim3(8 * tb * sp), dim3(512), PP_SMEM, s, a, b - tb, sp);
+      hipLaunchKernelGGL(attn_merge_kernel, dim3(8 * tb), dim3(256), 0, s, a, b - tb, sp, tb);
+    }
+  }
   return hipGetLastError();
 }

@@ -36,7 +36,9 @@ struct AttnArgs {
   int Lq, H;
   float scale;                     // softmax scale (1/sqrt(128))
   int cross;                       // 1: text cross-attention launch (symbol tag only)
+  float* split_ws; size_t split_ws_bytes;   // optional scratch for the split-KV tail round (nullptr: never split)
 };
+size_t mmpl_attention_split_ws_bytes();     // upper bound of what a launch can use
 hipError_t mmpl_launch_attention(const AttnArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- norms / rope / elementwise (elementwise.hip)

@@ -175,3 +175,33 @@ def test_qknorm_rope_kvwrite(lib, H, lat, frames):
         assert torch.equal(vc[s * S:(s + 1) * S].cpu(), oc[i * S:(i + 1) * S, 2 * d:])
     assert torch.equal(qkv[:, d:].cpu(), oc[:, d:])          # k, v inputs untouched
     assert kc[:3 * S].abs().sum().item() == 0 and kc[(3 + nF) * S:].abs().sum().item() == 0
+
+
+def test_attention_split_kv_tail_round(lib):
+    """A query-block count that leaves a partial last round of one-block-per-CU (41 blocks per XCD on 32 CUs): with a
+    workspace the 9 leftover blocks of every XCD run as 3 KV-range partials + merge.  Result vs fp32 and vs the unsplit
+    launch (same tolerance class; accumulation order differs)."""
+    from mmpl_amd import _lib
+    from oracle import wan_dit_ref as W
+    torch.manual_seed(11)
+    dev = "cuda:0"
+    H, S, n_pages, Lq = 8, 640, 3, 256 * 41 - 57
+    d = H * 128
+    q = torch.randn(Lq, d, device=dev).to(BF)
+    kc = torch.randn(n_pages * S, d, device=dev).to(BF)
+    vc = torch.randn(n_pages * S, d, device=dev).to(BF)
+    kp = (C.c_void_p * n_pages)(*[kc[i * S:].data_ptr() for i in range(n_pages)])
+    vp = (C.c_void_p * n_pages)(*[vc[i * S:].data_ptr() for i in range(n_pages)])
+    o_ws = torch.zeros(Lq, d, device=dev, dtype=BF)
+    o_plain = torch.zeros_like(o_ws)
+    ws = torch.empty(lib.mmpl_attn_workspace_bytes(), dtype=torch.uint8, device=dev)
+    _lib.check(lib.mmpl_attn_fwd_ws(_lib.ptr(q), d, _lib.ptr(o_ws), d, kp, vp, d, d, n_pages, S, Lq, H, 1.0 / math.sqrt(128),
+                                    _lib.ptr(ws), ws.numel(), _sp()))
+    _lib.check(lib.mmpl_attn_fwd(_lib.ptr(q), d, _lib.ptr(o_plain), d, kp, vp, d, d, n_pages, S, Lq, H, 1.0 / math.sqrt(128), _sp()))
+    torch.cuda.synchronize()
+    n_diff_rows = int((o_ws != o_plain).any(dim=1).sum())
+    assert 0 < n_diff_rows <= 9 * 256              # only (some of) the tail blocks' rows went through the split path
+    rows = torch.cat([torch.arange(0, 300), torch.arange(Lq - 2400, Lq)])          # head of the grid + the tail blocks
+    ref32 = W.sdpa_fp32(q[rows].reshape(1, -1, H, 128).cpu(), kc.reshape(1, -1, H, 128).cpu(), vc.reshape(1, -1, H, 128).cpu()).reshape(-1, d)
+    assert rel_l2(o_ws[rows], ref32) < 1e-2 and rel_l2(o_plain[rows], ref32) < 1e-2
+    assert rel_l2(o_ws, o_plain) < 3e-3
