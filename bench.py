@@ -286,7 +286,7 @@ def main():
                 st = json.load(open(pmc))["stages"]
                 traffic = sum(st[k]["hbm_bytes"] for k in ("s0", "s1", "s2", "s3")) / 4.0
                 traffic_src = "profiles/r01f_pmc_attention_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, mean of s0..s3)"
-            res["roofline"] = {"bound": "mfma", "kernel": "attn_pp_kernel (self-attention over the KV-slot page table)",
+            res["roofline"] = {"bound": "mfma", "kernel": "attn_pp_kernel (self-attention over the KV-slot page table; one op = main launch + split-KV tail launch + merge)",
                                "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
                                "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
                                "avg_launch_ms": a["ms"] / a["launches"], "launches": a["launches"],
