@@ -103,6 +103,13 @@ typedef struct MmplUniPCStep {
 } MmplUniPCStep;
 int mmpl_cfg_unipc_step(const void* flow_cond, const void* flow_uncond, void* x, void* m0, void* m1, void* last_sample,
                         size_t n, const MmplUniPCStep* s, mmpl_stream_t stream);
+/* Device-resident form, for ONE hipGraph per denoise step (2 DiT forwards + this) replayed sampling_steps times with no
+ * host work in between: the scalars of step *step_dev are read from table_dev[*step_dev] (n_steps entries, device memory),
+ * then *step_dev += 1 and the next step's timestep (timestep_table_dev[*step_dev]) is written to timestep_dev[0..n_timestep)
+ * -- the tensor the forwards of the next replay read. */
+int mmpl_cfg_unipc_step_table(const void* flow_cond, const void* flow_uncond, void* x, void* m0, void* m1, void* last_sample,
+                              size_t n, const MmplUniPCStep* table_dev, int* step_dev, float* timestep_dev,
+                              const float* timestep_table_dev, int n_timestep, int n_steps, mmpl_stream_t stream);
 
 /* ---- Wan 3D causal VAE (wan/modules/vae.py:483-569 behind WanVAEWrapper, utils/wan_wrapper.py:54-113) ----
  * Weights: mmpl_vae_num_weights() dev pointers in the reference state_dict order (mmpl_vae_weight_name(i)); conv weights

@@ -449,4 +449,18 @@ int mmpl_cfg_unipc_step(const void* flow_cond, const void* flow_uncond, void* x,
   return 0;
 }
 
+int mmpl_cfg_unipc_step_table(const void* flow_cond, const void* flow_uncond, void* x, void* m0, void* m1, void* last_sample,
+                              size_t n, const MmplUniPCStep* table_dev, int* step_dev, float* timestep_dev,
+                              const float* timestep_table_dev, int n_timestep, int n_steps, mmpl_stream_t stream) {
+  if (!table_dev || !step_dev || !timestep_dev || !timestep_table_dev || n_steps < 1 || n_timestep < 1)
+    return fail("mmpl_cfg_unipc_step_table", "bad arguments");
+  static_assert(sizeof(MmplUniPCStep) == sizeof(UniPCStepDev), "table layout");
+  UniPCArgs a = {};
+  a.flow_c = (const bf16_t*)flow_cond; a.flow_u = (const bf16_t*)flow_uncond; a.x = (bf16_t*)x;
+  a.m0 = (bf16_t*)m0; a.m1 = (bf16_t*)m1; a.last_sample = (bf16_t*)last_sample; a.n = n;
+  HIP_TRY(mmpl_launch_unipc_table(a, (const UniPCStepDev*)table_dev, step_dev, timestep_dev, timestep_table_dev, n_timestep, n_steps,
+                                  (hipStream_t)stream), "mmpl_cfg_unipc_step_table");
+  return 0;
+}
+
 }  // extern "C"

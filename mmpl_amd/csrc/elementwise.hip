@@ -202,7 +202,7 @@ __global__ void silu_kernel(const bf16_t* x, bf16_t* y, size_t n) {
 // ------------------------------------------------------------------ CFG + FlowUniPC (order <= 2, bh2, predict_x0)
 // Every tensor op of fm_solvers_unipc.py:315-331 / 486-626 / 350-484 on a bf16 tensor rounds to bf16; this kernel
 // performs the same chain per element with the same rounding points.  Scalars come from the host scheduler.
-__global__ void unipc_kernel(UniPCArgs a) {
+MMPL_DEV void unipc_body(const UniPCArgs& a) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
     float flow = bf2f(a.flow_c[i]);
     if (a.flow_u) {
@@ -235,6 +235,21 @@ __global__ void unipc_kernel(UniPCArgs a) {
     }
     a.x[i] = f2bf(xt);
   }
+}
+__global__ void unipc_kernel(UniPCArgs a) { unipc_body(a); }
+__global__ void unipc_table_kernel(UniPCArgs a, const UniPCStepDev* table, const int* step) {
+  const UniPCStepDev st = table[*step];
+  a.guidance = st.guidance; a.sigma_cur = st.sigma_cur; a.use_corrector = st.use_corrector; a.corr_order = st.corr_order;
+  a.c_c1 = st.c_c1; a.c_c2 = st.c_c2; a.c_c3 = st.c_c3; a.c_inv_rk = st.c_inv_rk; a.c_rho0 = st.c_rho0; a.c_rho_last = st.c_rho_last;
+  a.pred_order = st.pred_order; a.p_c1 = st.p_c1; a.p_c2 = st.p_c2; a.p_c3 = st.p_c3; a.p_inv_rk = st.p_inv_rk;
+  unipc_body(a);
+}
+__global__ void unipc_advance_kernel(int* step, float* t_out, const float* t_tab, int n_t, int n_steps) {
+  const int nxt = *step + 1;
+  __syncthreads();
+  if (threadIdx.x == 0) *step = nxt;
+  const float t = t_tab[nxt < n_steps ? nxt : n_steps - 1];
+  for (int i = threadIdx.x; i < n_t; i += blockDim.x) t_out[i] = t;
 }
 
 inline int grid_for(size_t n, int block = 256) {
@@ -307,5 +322,11 @@ hipError_t mmpl_launch_silu(const bf16_t* x, bf16_t* y, size_t n, hipStream_t s)
 }
 hipError_t mmpl_launch_unipc(const UniPCArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(unipc_kernel, dim3(grid_for(a.n)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t mmpl_launch_unipc_table(const UniPCArgs& a, const UniPCStepDev* table, int* step, float* t_out, const float* t_tab,
+                                   int n_t, int n_steps, hipStream_t s) {
+  hipLaunchKernelGGL(unipc_table_kernel, dim3(grid_for(a.n)), dim3(256), 0, s, a, table, step);
+  hipLaunchKernelGGL(unipc_advance_kernel, dim3(1), dim3(64), 0, s, step, t_out, t_tab, n_t, n_steps);
   return hipGetLastError();
 }

@@ -96,3 +96,12 @@ struct UniPCArgs {
   int pred_order; float p_c1, p_c2, p_c3, p_inv_rk;
 };
 hipError_t mmpl_launch_unipc(const UniPCArgs& a, hipStream_t s);
+// Device-resident form for a hipGraph of a whole denoise step: the scalars of step *step come from table[*step] (same
+// layout as MmplUniPCStep), then *step is advanced and the NEXT step's timestep is written to t_out[0..n_t) (the tensor
+// the two DiT forwards of the next replay read).  `a` carries the pointers and n only.
+struct UniPCStepDev {
+  float guidance, sigma_cur; int use_corrector, corr_order; float c_c1, c_c2, c_c3, c_inv_rk, c_rho0, c_rho_last;
+  int pred_order; float p_c1, p_c2, p_c3, p_inv_rk;
+};
+hipError_t mmpl_launch_unipc_table(const UniPCArgs& a, const UniPCStepDev* table, int* step, float* t_out, const float* t_tab,
+                                   int n_t, int n_steps, hipStream_t s);

@@ -6,7 +6,8 @@ Same constructor / ``inference()`` signature, attributes (``generator_cond``, ``
 underneath, MI355X-first:
   * one DiT forward = one C call (``mmpl_dit_forward``), K/V read in place through the slot table -- no gather copies,
     no host syncs inside a forward;
-  * CFG + UniPC = one fused kernel per step (``mmpl_cfg_unipc_step``);
+  * CFG + UniPC = one fused kernel per step (``mmpl_cfg_unipc_step``); with hipGraphs on, a whole denoise step (both
+    forwards + that kernel, its scalars and the next timestep read from device tables) is ONE graph replayed 50 times;
   * nothing is shuffled to the CPU (T5 / VAE stay resident: 288 GB HBM);
   * the literals 1560 / 40x128 / 40 blocks are derived from a ``Geometry`` and the model config;
   * the hand-off is delivered to ``self.handoff_sink`` (default: ``torch.save(self.save)`` like the reference; the
@@ -64,6 +65,7 @@ class CausalFPSInferencePipeline(torch.nn.Module):
         self.handoff_sink: Optional[Callable[[torch.Tensor], None]] = None
         self.renoise_override = None      # tests: {frame: [1,16,h,w]} instead of torch.randn_like draws
         self.use_graphs = True            # one hipGraph per (stage, cond|uncond) forward, replayed 50 + 1 times
+        self.step_graphs = True           # ... and one per whole denoise step (2 forwards + CFG/UniPC) for the 50 steps
         self.cfg_pair = None              # mmpl_amd.handoff.CfgPair: this rank runs only the cond (role 0) / uncond (role 1) branch
 
         # ---- "add new noise on previous frames" schedule (casual_fps_inference.py:93-108); the randint keeps the
@@ -179,24 +181,40 @@ class CausalFPSInferencePipeline(torch.nn.Module):
                 # in a CfgPair the forward writes a private buffer and the all-gather fills both halves of `flow`
                 outs = [flow[i] for _, _, _, i in branches] if pair is None else [torch.empty_like(latents)]
                 timestep = torch.empty([1, len(frames)], device=dev, dtype=torch.float32)
-                graphs = None
+                graphs, step_graph = None, None
                 if self.use_graphs:
                     starts = [f * S for f in frames]
                     timestep.fill_(float(sample_scheduler.timesteps[0]))
                     graphs = [self.generator_cond.capture(latents, d, timestep, kv, cross, starts, o)
                               for (d, kv, cross, _), o in zip(branches, outs)]
-                for t in sample_scheduler.timesteps:
-                    timestep.fill_(float(t))
-                    if graphs is not None:
-                        for g in graphs:
-                            g.replay()
-                    else:
-                        for (d, kv, cross, _), o in zip(branches, outs):
-                            self._forward(latents, d, timestep, kv, cross, frames, o)
-                    if pair is not None:
-                        pair.exchange(outs[0], flow)
-                    # flow = uncond + g (cond - uncond); latents = scheduler.step(flow)  -- one fused kernel (:366-374)
-                    sample_scheduler.step_cfg(flow[0], flow[1], self.args.guidance_scale, latents)
+                    if pair is None and self.step_graphs:
+                        # ONE hipGraph per denoise step: both forwards + the fused CFG / UniPC update, whose scalars and
+                        # the next timestep live in device tables -- 50 replays with no host work in between
+                        sample_scheduler.build_step_table(self.args.guidance_scale, dev)
+                        sample_scheduler._ensure_state(latents)
+                        torch.cuda.synchronize(dev)
+                        step_graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(step_graph):
+                            for (d, kv, cross, _), o in zip(branches, outs):
+                                self._forward(latents, d, timestep, kv, cross, frames, o)
+                            sample_scheduler.step_cfg_table(flow[0], flow[1], latents, timestep)
+                if step_graph is not None:
+                    timestep.fill_(float(sample_scheduler.timesteps[0]))
+                    for _ in sample_scheduler.timesteps:
+                        step_graph.replay()
+                else:
+                    for t in sample_scheduler.timesteps:
+                        timestep.fill_(float(t))
+                        if graphs is not None:
+                            for g in graphs:
+                                g.replay()
+                        else:
+                            for (d, kv, cross, _), o in zip(branches, outs):
+                                self._forward(latents, d, timestep, kv, cross, frames, o)
+                        if pair is not None:
+                            pair.exchange(outs[0], flow)
+                        # flow = uncond + g (cond - uncond); latents = scheduler.step(flow)  -- one fused kernel (:366-374)
+                        sample_scheduler.step_cfg(flow[0], flow[1], self.args.guidance_scale, latents)
 
                 output[:, frames] = latents
                 if si == self.plan.handoff_stage:                             # t2v :380-383, i2v :340-343

@@ -150,6 +150,34 @@ class FlowUniPCMultistepScheduler:
                    "mmpl_cfg_unipc_step")
         return sample
 
+    # -- device-resident step table: one hipGraph per denoise step, replayed with no host work in between --------------
+    def build_step_table(self, guidance: float, device) -> None:
+        """Upload the scalars of ALL remaining steps (they depend only on the step index, never on data) plus the timestep
+        of every step; `step_cfg_table` then reads entry *counter on the device.  Host bookkeeping is advanced to the end."""
+        import copy
+        probe = copy.copy(self)
+        probe._state = None
+        n = len(self.timesteps) - self.step_index
+        rows = (_lib.MmplUniPCStep * n)()
+        for i in range(n):
+            rows[i] = probe.step_scalars(guidance)
+        raw = torch.frombuffer(bytearray(bytes(rows)), dtype=torch.uint8).clone()
+        self._table = raw.to(device)
+        self._t_table = torch.tensor([float(t) for t in self.timesteps[self.step_index:]], dtype=torch.float32, device=device)
+        self._counter = torch.zeros(1, dtype=torch.int32, device=device)
+        self._table_n = n
+
+    def step_cfg_table(self, flow_cond: torch.Tensor, flow_uncond: torch.Tensor, sample: torch.Tensor, timestep: torch.Tensor) -> None:
+        """CFG combine + scheduler step with device-resident scalars (capturable: no host value enters the launch);
+        advances the device step counter and writes the next step's timestep into `timestep` (float32, contiguous)."""
+        assert sample.is_contiguous() and sample.dtype == torch.bfloat16 and timestep.dtype == torch.float32 and timestep.is_contiguous()
+        self._ensure_state(sample)
+        m0, m1, last = self._state
+        _lib.check(_lib.load().mmpl_cfg_unipc_step_table(
+            _lib.ptr(flow_cond), _lib.ptr(flow_uncond), _lib.ptr(sample), _lib.ptr(m0), _lib.ptr(m1), _lib.ptr(last), sample.numel(),
+            _lib.ptr(self._table), _lib.ptr(self._counter), _lib.ptr(timestep), _lib.ptr(self._t_table), timestep.numel(), self._table_n,
+            _lib.stream_ptr()), "mmpl_cfg_unipc_step_table")
+
     def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor, return_dict: bool = True):
         """Reference call shape (fm_solvers_unipc.py:655).  `timestep` is accepted and ignored like the reference's
         internal step counter does after the first call."""

@@ -55,3 +55,26 @@ def test_unipc_single_steps_bit_level():
             s._state[1].copy_(o.model_outputs[-2])
         s._state[2].copy_(o.last_sample)
     assert bad < 2e-3, bad
+
+
+def test_device_table_step_equals_host_scalar_step():
+    """mmpl_cfg_unipc_step_table (scalars, step counter and next timestep on the device: the form captured in the
+    per-denoise-step hipGraph) is bit-identical to mmpl_cfg_unipc_step over all 50 steps, and leaves the right timestep."""
+    from mmpl_amd.scheduler import FlowUniPCMultistepScheduler
+    torch.manual_seed(0)
+    dev = "cuda:0"
+    x0 = torch.randn(3, 16, 8, 12, device=dev).bfloat16()
+    flows = [(torch.randn_like(x0), torch.randn_like(x0)) for _ in range(50)]
+    a = FlowUniPCMultistepScheduler(1000, 2, 1.0)
+    a.set_timesteps(50, shift=5.0)
+    b = FlowUniPCMultistepScheduler(1000, 2, 1.0)
+    b.set_timesteps(50, shift=5.0)
+    xa, xb = x0.clone(), x0.clone()
+    t = torch.full([3], float(b.timesteps[0]), dtype=torch.float32, device=dev)
+    b.build_step_table(5.0, dev)
+    for i, (fc, fu) in enumerate(flows):
+        a.step_cfg(fc, fu, 5.0, xa)
+        assert float(t[0]) == float(b.timesteps[i])              # the forwards of replay i would read this
+        b.step_cfg_table(fc, fu, xb, t)
+        assert torch.equal(xa, xb), i
+    assert int(b._counter.item()) == 50
