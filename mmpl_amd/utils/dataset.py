@@ -10,24 +10,40 @@ from PIL import Image
 from torch.utils.data import Dataset
 
 
+def _read_lines(path):
+    with open(path, encoding="utf-8") as fh:
+        return [ln.rstrip() for ln in fh]
+
+
 class TextDataset(Dataset):
+    """One prompt per line (trailing whitespace stripped, blank lines kept); optionally a second file with one
+    "extended" prompt per line, which must have the same number of lines.  Items: {"prompts", "idx"[, "extended_prompts"]}."""
+
     def __init__(self, prompt_path, extended_prompt_path=None):
-        with open(prompt_path, encoding="utf-8") as f:
-            self.prompt_list = [line.rstrip() for line in f]
-        self.extended_prompt_list = None
-        if extended_prompt_path is not None:
-            with open(extended_prompt_path, encoding="utf-8") as f:
-                self.extended_prompt_list = [line.rstrip() for line in f]
-            assert len(self.extended_prompt_list) == len(self.prompt_list)
+        prompts = _read_lines(prompt_path)
+        extended = _read_lines(extended_prompt_path) if extended_prompt_path is not None else None
+        if extended is not None and len(extended) != len(prompts):
+            raise AssertionError(f"{extended_prompt_path}: {len(extended)} lines, {prompt_path}: {len(prompts)}")
+        self._rows = [(p, None if extended is None else extended[i]) for i, p in enumerate(prompts)]
+        self._has_extended = extended is not None
+
+    @property
+    def prompt_list(self):
+        return [p for p, _ in self._rows]
+
+    @property
+    def extended_prompt_list(self):
+        return [e for _, e in self._rows] if self._has_extended else None
 
     def __len__(self):
-        return len(self.prompt_list)
+        return len(self._rows)
 
     def __getitem__(self, idx):
-        batch = {"prompts": self.prompt_list[idx], "idx": idx}
-        if self.extended_prompt_list is not None:
-            batch["extended_prompts"] = self.extended_prompt_list[idx]
-        return batch
+        prompt, ext = self._rows[idx]
+        item = {"prompts": prompt, "idx": idx}
+        if self._has_extended:
+            item["extended_prompts"] = ext
+        return item
 
 
 class TextImagePairDataset(Dataset):
