@@ -94,3 +94,53 @@ def test_cfg_pairs_two_lanes(tmp_path):
     assert not torch.equal(r[0]["noise"], r[2]["noise"])
     assert r[0]["got"] is None and r[1]["got"] is None
     assert torch.equal(r[2]["got"], torch.full(SHAPE, 7.0, dtype=torch.bfloat16)) and torch.equal(r[3]["got"], r[2]["got"])
+
+
+def _wavefront_worker(rank, world, port, out_path, n_chunks):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        from mmpl_amd.handoff import run_chunk_wavefront
+        pair, heads, lay = CfgPair.build(world, "cpu", cfg_split=True)
+        lane, n_lanes = lay["lane_of"][rank], world // 2
+        ho = ChunkHandoff(SHAPE, "cpu", group=heads) if pair.role == 0 else None
+        log = []
+
+        def make_chunk(c, initial, sink):
+            # what pipeline.inference does in a CfgPair: role 0's initial latent overwrites role 1's placeholder, both ranks
+            # compute the same chunk, only role 0 delivers the hand-off
+            if initial is not None:
+                initial = pair.broadcast(initial)
+            base = torch.full(SHAPE, float(c + 1), dtype=torch.bfloat16)
+            if initial is not None:
+                base = base + initial.float().mean().to(torch.bfloat16)
+            sink(base)
+            log.append((c, None if initial is None else float(initial.float().mean())))
+            return base[:, :2].clone()
+
+        res = run_chunk_wavefront(make_chunk, n_chunks, ho, to_initial=lambda t: t[:, :2], pair=pair, lane=lane, n_lanes=n_lanes,
+                                  initial_like=torch.empty((1, 2) + SHAPE[2:], dtype=torch.bfloat16))
+        torch.save({"log": log, "res": res}, f"{out_path}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_wavefront_with_cfg_pairs_four_ranks(tmp_path):
+    """run_chunk_wavefront over 2 lanes x (cond, uncond): 5 chunks; the uncond ranks follow their lane head chunk by chunk
+    (same chunk ids, same initial latents) and only rank 0 gathers the results."""
+    out = str(tmp_path / "w")
+    mp.spawn(_wavefront_worker, args=(4, _free_port(), out, 5), nprocs=4, join=True)
+    r = [torch.load(f"{out}.{k}") for k in range(4)]
+    assert [c for c, _ in r[0]["log"]] == [0, 2, 4] and [c for c, _ in r[2]["log"]] == [1, 3]
+    assert r[1]["log"] == r[0]["log"] and r[3]["log"] == r[2]["log"]          # uncond partners saw the same chunks / initial latents
+    assert r[1]["res"] is None and r[2]["res"] is None and r[3]["res"] is None and len(r[0]["res"]) == 5
+    # the dependency chain ran through both lanes: chunk c's anchors = c + 1 + mean(initial from chunk c-1)
+    want, prev = [], None
+    for c in range(5):
+        v = float(c + 1) + (0.0 if prev is None else prev)
+        v = float(torch.tensor(v).to(torch.bfloat16))
+        want.append(v)
+        prev = v
+    got = [float(t.float().mean()) for t in r[0]["res"]]
+    assert got == want
