@@ -24,12 +24,35 @@ template <int EPI>
 MMPL_DEV void gemm_epilogue(const GemmArgs& g, const f32x4 (&acc)[4][4], int mw, int nw, int frow, int fchunk) {
   const int m0 = 0, n0 = 0, wm = 0, wn = 0;
   (void)m0; (void)n0; (void)wm; (void)wn;
-  // ---- epilogue: lane holds, per fragment (i,j), column m = ..+(lane&15) and rows n = ..+4*(lane>>4)+{0..3}
+  // ---- epilogue: lane holds, per fragment (i,j), column m = ..+(lane&15) and rows n = ..+4*(lane>>4)+{0..3}.
+  // Pass 1 issues every load of the tile (bias, residual, gate) before pass 2 stores anything: the residual usually IS the
+  // output buffer (x += ...), so with loads and stores interleaved per fragment hipcc must keep each load behind the previous
+  // store and the tile's epilogue becomes 16 dependent HBM round trips; like this they are all in flight at once.
+  uint2 bias4[4], res4[4][4], gate4[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = nw + 16 * j + 4 * fchunk;
+    bias4[j] = (EPI != EPI_F32_SCALE && g.bias && n < g.N) ? *reinterpret_cast<const uint2*>(g.bias + n) : uint2{0u, 0u};
+  }
+  if (EPI == EPI_GATE_RES || EPI == EPI_RES) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mw + 16 * i + frow;
+      const int frame = (EPI == EPI_GATE_RES && m < g.M) ? (m / g.rows_per_frame) : 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = nw + 16 * j + 4 * fchunk;
+        const bool ok = m < g.M && n < g.N;
+        res4[i][j] = ok ? *reinterpret_cast<const uint2*>(g.res + (size_t)m * g.ldres + n) : uint2{0u, 0u};
+        if (EPI == EPI_GATE_RES)
+          gate4[i][j] = ok ? *reinterpret_cast<const uint2*>(g.gate + (size_t)frame * g.gate_frame_stride + n) : uint2{0u, 0u};
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = mw + 16 * i + frow;
     if (m >= g.M) continue;
-    const int frame = (EPI == EPI_GATE_RES) ? (m / g.rows_per_frame) : 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = nw + 16 * j + 4 * fchunk;
@@ -43,11 +66,8 @@ MMPL_DEV void gemm_epilogue(const GemmArgs& g, const f32x4 (&acc)[4][4], int mw,
       }
       float v[4];
       {
-        float b[4] = {0.f, 0.f, 0.f, 0.f};
-        if (g.bias) {
-          const uint2 bb = *reinterpret_cast<const uint2*>(g.bias + n);
-          b[0] = bf2f(bb.x & 0xffff); b[1] = bf2f(bb.x >> 16); b[2] = bf2f(bb.y & 0xffff); b[3] = bf2f(bb.y >> 16);
-        }
+        const uint2 bb = bias4[j];
+        const float b[4] = {bf2f(bb.x & 0xffff), bf2f(bb.x >> 16), bf2f(bb.y & 0xffff), bf2f(bb.y >> 16)};
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = rbf(acc[i][j][r] + b[r]);  // Linear output rounds to bf16
       }
@@ -58,10 +78,10 @@ MMPL_DEV void gemm_epilogue(const GemmArgs& g, const f32x4 (&acc)[4][4], int mw,
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = silu(v[r]);
       } else if (EPI == EPI_GATE_RES || EPI == EPI_RES) {
-        const uint2 xx = *reinterpret_cast<const uint2*>(g.res + (size_t)m * g.ldres + n);
+        const uint2 xx = res4[i][j];
         float x[4] = {bf2f(xx.x & 0xffff), bf2f(xx.x >> 16), bf2f(xx.y & 0xffff), bf2f(xx.y >> 16)};
         if (EPI == EPI_GATE_RES) {
-          const uint2 ee = *reinterpret_cast<const uint2*>(g.gate + (size_t)frame * g.gate_frame_stride + n);
+          const uint2 ee = gate4[i][j];
           float e[4] = {bf2f(ee.x & 0xffff), bf2f(ee.x >> 16), bf2f(ee.y & 0xffff), bf2f(ee.y >> 16)};
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = rbf(v[r] * e[r]);  // y * e rounds, then x + (.) rounds
