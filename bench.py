@@ -245,11 +245,8 @@ def main():
             vae_s = f"failed: {e!r}"
     # per-stage mean step time; a stage the K steps did not reach is priced at the measured FLOP rate of the others
     stage_flops = [dit_forward_flops(cfg, S, q, kv) for q, kv in stage_shapes]
-    per_stage = [[step_s[i] for i in range(args.steps) if (args.warmup + i) % 4 == k] for k in range(4)]
-    seen = [k for k in range(4) if per_stage[k]]
-    rate = sum(stage_flops[k] for k in seen) / sum(sum(per_stage[k]) / len(per_stage[k]) for k in seen)
-    stage_s = [sum(per_stage[k]) / len(per_stage[k]) if per_stage[k] else stage_flops[k] / rate for k in range(4)]
-    chunk_s = 51.0 * sum(stage_s)                  # 4 stages x (50 denoise steps + 1 refresh pair) = 204 step-equivalents
+    from mmpl_amd.stage_plan import assemble_chunk_seconds
+    stage_s, chunk_s = assemble_chunk_seconds(step_s, args.warmup, stage_flops)     # 4 stages x (50 denoise steps + 1 refresh pair)
     if dist is not None:
         tt = torch.tensor([elapsed, chunk_s], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -97,3 +97,16 @@ def dit_forward_flops(cfg: dict, frame_seqlen: int, n_q_frames: int, n_kv_frames
 T2V_STAGE_SHAPES = [(2, 2), (7, 9), (6, 13), (6, 21)]
 # I2V denoise stages s1..s4 (s0 = the image latent, refresh pass only; frames 19, 20 stay visible in s3): SURVEY.md App. A
 I2V_STAGE_SHAPES = [(1, 2), (7, 9), (6, 15), (6, 21)]
+
+
+def assemble_chunk_seconds(step_seconds, first_step_index: int, stage_flops, steps_per_stage: int = 51):
+    """bench.py: K timed steps rotate through the four stage shapes (step i runs stage (first_step_index + i) % 4).
+    Returns (per-stage mean step time, chunk time = steps_per_stage * sum of them).  A stage the K steps never reached is
+    priced at the FLOP rate measured on the others, so any K >= 1 gives an unbiased estimate."""
+    per_stage = [[t for i, t in enumerate(step_seconds) if (first_step_index + i) % 4 == k] for k in range(4)]
+    seen = [k for k in range(4) if per_stage[k]]
+    if not seen:
+        raise ValueError("no timed steps")
+    rate = sum(stage_flops[k] for k in seen) / sum(sum(per_stage[k]) / len(per_stage[k]) for k in seen)
+    stage_s = [sum(per_stage[k]) / len(per_stage[k]) if per_stage[k] else stage_flops[k] / rate for k in range(4)]
+    return stage_s, float(steps_per_stage) * sum(stage_s)

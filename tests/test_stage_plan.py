@@ -53,3 +53,20 @@ def test_flop_table_known_answers(model, S, expect_tf):
     got = [dit_forward_flops(WAN_CONFIGS[model], S, q, kv) / 1e12 for q, kv in T2V_STAGE_SHAPES]
     for g, e in zip(got, expect_tf):
         assert abs(g - e) / e < 2e-3, (got, expect_tf)
+
+
+def test_bench_chunk_time_assembly():
+    from mmpl_amd.stage_plan import T2V_STAGE_SHAPES, assemble_chunk_seconds, dit_forward_flops
+    from mmpl_amd.synthetic import WAN_CONFIGS
+    fl = [dit_forward_flops(WAN_CONFIGS["14B"], 3600, q, kv) for q, kv in T2V_STAGE_SHAPES]
+    true = [0.5, 2.4, 2.6, 3.6]
+    # K = 8 from warm-up 4: every stage twice
+    st, chunk = assemble_chunk_seconds([true[(4 + i) % 4] for i in range(8)], 4, fl)
+    assert st == true and abs(chunk - 51 * sum(true)) < 1e-9
+    # K = 5 from warm-up 1: stage 1 twice, no bias from the uneven mix
+    st, chunk = assemble_chunk_seconds([true[(1 + i) % 4] for i in range(5)], 1, fl)
+    assert st == true
+    # K = 2: stages 0 and 1 measured, 2 and 3 priced at the measured FLOP rate (exact when time is proportional to FLOPs)
+    prop = [f / 1e15 for f in fl]
+    st, chunk = assemble_chunk_seconds(prop[:2], 0, fl)
+    assert all(abs(a - b) < 1e-9 for a, b in zip(st, prop))
