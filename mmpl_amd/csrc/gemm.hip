@@ -586,10 +586,13 @@ hipError_t launch_v2(const GemmArgs& g, hipStream_t s) {
 
 template <int EPI>
 hipError_t launch(const GemmArgs& g, hipStream_t s) {
-  const bool big = g.batch <= 1 && g.M >= 1024 && g.N >= 256 && g.K >= 128 && !getenv("MMPL_GEMM_V1") && !getenv("MMPL_GEMM_V2");
-  if (big && !getenv("MMPL_GEMM_V4") && (long long)g.M * g.lda < (1ll << 31) && (long long)g.N * g.ldw < (1ll << 31)) return launch_v6<EPI>(g, s);
+  // kernel-selection overrides for A/B runs, read once per process
+  static const bool env_v1 = getenv("MMPL_GEMM_V1") != nullptr, env_v2 = getenv("MMPL_GEMM_V2") != nullptr,
+                    env_v4 = getenv("MMPL_GEMM_V4") != nullptr;
+  const bool big = g.batch <= 1 && g.M >= 1024 && g.N >= 256 && g.K >= 128 && !env_v1 && !env_v2;
+  if (big && !env_v4 && (long long)g.M * g.lda < (1ll << 31) && (long long)g.N * g.ldw < (1ll << 31)) return launch_v6<EPI>(g, s);
   if (big) return launch_v4<EPI>(g, s);
-  if (g.batch <= 1 && g.M >= 1024 && g.N >= 128 && g.K >= 128 && !getenv("MMPL_GEMM_V1")) return launch_v2<EPI>(g, s);
+  if (g.batch <= 1 && g.M >= 1024 && g.N >= 128 && g.K >= 128 && !env_v1) return launch_v2<EPI>(g, s);
   static bool attr_set = false;
   constexpr int smem = 4 * TILE_BYTES;
   if (!attr_set) {
