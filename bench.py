@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--mode", default="t2v", choices=["t2v", "i2v"], help="stage plan of the rotation (i2v: 1/7/6/6 query frames, BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="disable the per-kernel hipEvent pairs")
+    ap.add_argument("--profile-all", action="store_true",
+                    help="time every kernel class (adds gemm_tflops / kernel_time_share; ~0.5-1 %% slower than the default, "
+                         "which times the roofline kernel -- self-attention -- only)")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-region) VAE decode measurement")
     ap.add_argument("--cfg-split", action="store_true",
                     help="N/2 chunk lanes x (cond, uncond) rank pairs exchanging flow predictions every step "
@@ -203,7 +206,7 @@ def main():
     torch.cuda.current_stream().wait_stream(side)
     barrier()
     if not args.no_profile:
-        lib.mmpl_profile_enable(1)
+        lib.mmpl_profile_enable(1 if args.profile_all else ((1 << 1) << 1))      # default: kind 1 = self-attention only
     # the K timed steps keep rotating through the four stage shapes; every step is also bracketed by a HIP event pair so
     # that the chunk time can be assembled per stage (exact for any K, not only multiples of 4)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -291,8 +294,11 @@ def main():
                                "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
                                "avg_launch_ms": a["ms"] / a["launches"], "launches": a["launches"],
                                "algorithmic_flops_per_launch": a["flops"] / a["launches"]}
-            tot = sum(v["ms"] for v in prof.values())
-            res["kernel_time_share"] = {k: round(v["ms"] / tot, 4) for k, v in prof.items()}
+            # share of the timed wall clock spent in the roofline kernel (per rank; exact, unlike a share of timed kernels)
+            res["roofline"]["time_share_of_step"] = round(a["ms"] * 1e-3 / sum(step_s), 4)
+            if args.profile_all:
+                tot = sum(v["ms"] for v in prof.values())
+                res["kernel_time_share"] = {k: round(v["ms"] / tot, 4) for k, v in prof.items()}
             if "gemm" in prof:
                 g = prof["gemm"]
                 res["gemm_tflops"] = g["flops"] / (g["ms"] * 1e-3) / 1e12

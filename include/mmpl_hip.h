@@ -166,7 +166,9 @@ int mmpl_i2v_cross_attn(const void* x, int Lq, int dim, const void* wq, const vo
 
 /* Optional per-kernel-class hipEvent timing (bench.py's live roofline numbers; off by default, not thread-safe).
  * kinds: 0 gemm, 1 self-attention, 2 cross-attention, 3 layernorm, 4 qk-norm/rope/kv-write, 5 elementwise, 6 cfg+unipc,
- * 7 vae.  mmpl_profile_read synchronises the device, sums the event pairs recorded since enable/last read. */
+ * 7 vae.  on = 0 off, 1 every kind, > 1: only the kinds in the bit mask (on >> 1) (e.g. 2 << 1 | ... ; bench.py times the
+ * self-attention only unless --profile-all, an event pair per op costs ~0.5 % of a step when every op is timed).
+ * mmpl_profile_read synchronises the device, sums the event pairs recorded since enable/last read. */
 int mmpl_profile_enable(int on);
 int mmpl_profile_read(int n_kinds, double* ms, double* flops, long long* launches);
 

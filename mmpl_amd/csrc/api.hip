@@ -32,11 +32,12 @@ struct Prof {
   std::vector<int> kind;
   std::vector<double> flops;
   size_t used = 0;  // pairs
+  unsigned mask = ~0u;  // kinds that are timed (mmpl_profile_enable: on = 1 all kinds, on > 1 = bit mask << 1)
 } g_prof;
 struct ProfScope {
   hipStream_t s;
   bool active;
-  ProfScope(int kind, double flops, hipStream_t st) : s(st), active(g_prof.on) {
+  ProfScope(int kind, double flops, hipStream_t st) : s(st), active(g_prof.on && (g_prof.mask >> kind & 1)) {
     if (!active) return;
     if (g_prof.ev.size() < 2 * (g_prof.used + 1)) {
       hipEvent_t a, b;
@@ -93,6 +94,7 @@ extern "C" {
 
 int mmpl_profile_enable(int on) {
   g_prof.on = on != 0;
+  g_prof.mask = on > 1 ? (unsigned)on >> 1 : ~0u;
   g_prof.used = 0;
   return 0;
 }
