@@ -307,10 +307,20 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
       ProfScope ps(K_LAYERNORM, 0, s);
       HIP_TRY(mmpl_launch_layernorm(a, s), "norm1");
     }
-    TRY(gemm(w.xn, d, h->Lw(l, L_QKV_W), d, h->Lw(l, L_QKV_B), w.big, 3 * d, Lq, 3 * d, d, EPI_BIAS, nullptr, 0, nullptr, 0, 1, s));
+    {
+      // fused q|k|v projection; the V third goes straight into its KV-cache pages (V is cached unchanged,
+      // causal_fps_model.py:217), so the norm / RoPE pass below only touches q and k
+      GemmArgs g{w.xn, d, h->Lw(l, L_QKV_W), d, h->Lw(l, L_QKV_B), w.big, 3 * d, Lq, 3 * d, d, EPI_BIAS_VPAGES, nullptr, 0, nullptr, 0, S,
+                 1.0f, 0, 0, 0, 0, 0};
+      for (int i = 0; i < nF; ++i) g.v_dst[i] = persist ? vc + (size_t)write_slots[i] * S * d : w.vsc + (size_t)i * S * d;
+      g.v_col0 = 2 * d;
+      g.v_ld = d;
+      ProfScope ps(K_GEMM, 2.0 * Lq * 3.0 * d * d, s);
+      HIP_TRY(mmpl_launch_gemm(g, s), "qkv gemm");
+    }
     {
       QkNormArgs a = {};
-      a.q = w.big; a.ldq = 3 * d; a.k = w.big + d; a.ldk = 3 * d; a.v = w.big + 2 * d; a.ldv = 3 * d;
+      a.q = w.big; a.ldq = 3 * d; a.k = w.big + d; a.ldk = 3 * d; a.v = nullptr; a.ldv = 3 * d;
       a.wq = h->Lw(l, L_NQ); a.wk = h->Lw(l, L_NK); a.rows = Lq; a.d = d; a.eps = c.eps; a.rope = 1;
       a.cos_tab = h->cos_tab; a.sin_tab = h->sin_tab; a.rows_per_frame = S; a.grid_w = h->gw;
       for (int i = 0; i < nF; ++i) {
@@ -408,6 +418,7 @@ int mmpl_attn_fwd(const void* q, int ldq, void* o, int ldo, const void* const* k
 int mmpl_gemm(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N, int K,
               int epi, const void* res, int ldres, const void* gate, int gate_frame_stride, int rows_per_frame,
               mmpl_stream_t stream) {
+  if (epi < EPI_BIAS || epi > EPI_F32_SCALE) return fail("mmpl_gemm", "unknown epilogue");
   if ((epi == EPI_GATE_RES && (!res || !gate)) || (epi == EPI_RES && !res)) return fail("mmpl_gemm", "missing epilogue operand");
   return gemm((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (bf16_t*)C, ldc, M, N, K, epi,
               (const bf16_t*)res, ldres, (const bf16_t*)gate, gate_frame_stride, rows_per_frame, (hipStream_t)stream);

@@ -92,7 +92,12 @@ MMPL_DEV void gemm_epilogue(const GemmArgs& g, const f32x4 (&acc)[4][4], int mw,
       uint2 o;
       o.x = pack2bf(v[0], v[1]);
       o.y = pack2bf(v[2], v[3]);
-      *reinterpret_cast<uint2*>(g.C + (size_t)m * g.ldc + n) = o;
+      if (EPI == EPI_BIAS_VPAGES && n >= g.v_col0) {
+        const int fr = m / g.rows_per_frame;
+        *reinterpret_cast<uint2*>(g.v_dst[fr] + (size_t)(m - fr * g.rows_per_frame) * g.v_ld + (n - g.v_col0)) = o;
+      } else {
+        *reinterpret_cast<uint2*>(g.C + (size_t)m * g.ldc + n) = o;
+      }
     }
   }
 }
@@ -618,6 +623,7 @@ hipError_t mmpl_launch_gemm(const GemmArgs& g, hipStream_t s) {
     case EPI_GATE_RES: return launch<EPI_GATE_RES>(g, s);
     case EPI_RES: return launch<EPI_RES>(g, s);
     case EPI_F32_SCALE: return launch<EPI_F32_SCALE>(g, s);
+    case EPI_BIAS_VPAGES: return launch<EPI_BIAS_VPAGES>(g, s);
   }
   return hipErrorInvalidValue;
 }

@@ -5,7 +5,8 @@
 #include "common.h"
 
 // ---------------------------------------------------------------- GEMM (gemm.hip)
-enum GemmEpi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_SILU = 2, EPI_GATE_RES = 3, EPI_RES = 4, EPI_F32_SCALE = 5 };
+enum GemmEpi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_SILU = 2, EPI_GATE_RES = 3, EPI_RES = 4, EPI_F32_SCALE = 5,
+               EPI_BIAS_VPAGES = 6 };   // bias; columns >= v_col0 go to per-frame pages instead of C (the V third of the fused qkv)
 struct GemmArgs {
   const bf16_t* A; int lda;      // [M, K]
   const bf16_t* W; int ldw;      // [N, K]  (nn.Linear weight)
@@ -21,6 +22,8 @@ struct GemmArgs {
   int group;                     // M-tile group size of the block order (set by the launcher)
   int batch;                     // > 1: batched (blockIdx.y); element strides below; small-problem kernel only
   long sA, sW, sC;
+  // EPI_BIAS_VPAGES: row m, column n >= v_col0 is written to v_dst[m / rows_per_frame] + (m % rows_per_frame) * v_ld + n - v_col0
+  bf16_t* v_dst[8]; int v_col0, v_ld;
 };
 hipError_t mmpl_launch_gemm(const GemmArgs& g, hipStream_t s);
 
