@@ -77,6 +77,14 @@ int mmpl_attn_fwd_ws(const void* q, int ldq, void* o, int ldo, const void* const
                      int ldk, int ldv, int n_pages, int page_rows, int Lq, int num_heads, float softmax_scale,
                      void* workspace, size_t workspace_bytes, mmpl_stream_t stream);
 
+/* Same, with the kernel chosen by the caller (tests and A/B runs): variant 0 = what mmpl_attn_fwd_ws picks (the
+ * 64-query-rows-per-wave kernel), 1 = lock-step 8 x 32 rows (the kernel the text cross-attention uses), 2 = ping-pong
+ * 8 x 32 rows, 3 = 4 waves x 64 rows.  cross != 0 tags the launch as a text cross-attention launch (kernel symbol of
+ * variant 1 only).  Unknown variant: error. */
+int mmpl_attn_fwd_variant(const void* q, int ldq, void* o, int ldo, const void* const* k_pages, const void* const* v_pages,
+                          int ldk, int ldv, int n_pages, int page_rows, int Lq, int num_heads, float softmax_scale,
+                          void* workspace, size_t workspace_bytes, int variant, int cross, mmpl_stream_t stream);
+
 /* nn.Linear (+ fused epilogue). epi: 0 bias, 1 bias+GELU(tanh), 2 bias+SiLU, 3 x + (y*gate[frame]) , 4 x + y */
 int mmpl_gemm(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N, int K,
               int epi, const void* res, int ldres, const void* gate, int gate_frame_stride, int rows_per_frame,

@@ -23,7 +23,8 @@ int mmpl_set_error(const char* where, const char* what) { return fail(where, wha
     if (e__ != hipSuccess) return fail(where, hipGetErrorString(e__)); \
   } while (0)
 
-// ---- optional per-kernel-class timing (bench / profiling only; not thread-safe, off by default)
+// ---- optional per-kernel-class timing (bench / profiling only; per host thread, off by default; launches recorded
+// while the stream is being captured into a hipGraph are not timed -- an event pair inside a graph cannot be read back)
 enum { K_GEMM, K_ATTN_SELF, K_ATTN_CROSS, K_LAYERNORM, K_QKNORM, K_ELEMENTWISE, K_UNIPC, K_VAE, K_NKINDS };
 namespace {
 struct Prof {
@@ -33,11 +34,16 @@ struct Prof {
   std::vector<double> flops;
   size_t used = 0;  // pairs
   unsigned mask = ~0u;  // kinds that are timed (mmpl_profile_enable: on = 1 all kinds, on > 1 = bit mask << 1)
-} g_prof;
+};
+thread_local Prof g_prof;
 struct ProfScope {
   hipStream_t s;
   bool active;
   ProfScope(int kind, double flops, hipStream_t st) : s(st), active(g_prof.on && (g_prof.mask >> kind & 1)) {
+    if (active) {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) active = false;
+    }
     if (!active) return;
     if (g_prof.ev.size() < 2 * (g_prof.used + 1)) {
       hipEvent_t a, b;
@@ -395,17 +401,27 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
 // ------------------------------------------------------------------------------------------------ single kernels
 size_t mmpl_attn_workspace_bytes(void) { return mmpl_attention_split_ws_bytes(); }
 
-int mmpl_attn_fwd_ws(const void* q, int ldq, void* o, int ldo, const void* const* k_pages, const void* const* v_pages,
-                     int ldk, int ldv, int n_pages, int page_rows, int Lq, int num_heads, float softmax_scale,
-                     void* workspace, size_t workspace_bytes, mmpl_stream_t stream) {
+int mmpl_attn_fwd_variant(const void* q, int ldq, void* o, int ldo, const void* const* k_pages, const void* const* v_pages,
+                          int ldk, int ldv, int n_pages, int page_rows, int Lq, int num_heads, float softmax_scale,
+                          void* workspace, size_t workspace_bytes, int variant, int cross, mmpl_stream_t stream) {
   if (n_pages < 1 || n_pages > MMPL_MAX_PAGES) return fail("mmpl_attn_fwd", "n_pages out of range");
+  if (variant < ATTN_AUTO || variant > ATTN_W64) return fail("mmpl_attn_fwd", "unknown kernel variant");
   AttnArgs a = {};
+  a.variant = variant;
+  a.cross = cross != 0;
   a.q = (const bf16_t*)q; a.ldq = ldq; a.o = (bf16_t*)o; a.ldo = ldo; a.ldk = ldk; a.ldv = ldv; a.n_pages = n_pages;
   a.page_rows = page_rows; a.Lq = Lq; a.H = num_heads; a.scale = softmax_scale;
   a.split_ws = (float*)workspace; a.split_ws_bytes = workspace ? workspace_bytes : 0;
   for (int i = 0; i < n_pages; ++i) { a.k_pages[i] = (const bf16_t*)k_pages[i]; a.v_pages[i] = (const bf16_t*)v_pages[i]; }
   HIP_TRY(mmpl_launch_attention(a, (hipStream_t)stream), "mmpl_attn_fwd");
   return 0;
+}
+
+int mmpl_attn_fwd_ws(const void* q, int ldq, void* o, int ldo, const void* const* k_pages, const void* const* v_pages,
+                     int ldk, int ldv, int n_pages, int page_rows, int Lq, int num_heads, float softmax_scale,
+                     void* workspace, size_t workspace_bytes, mmpl_stream_t stream) {
+  return mmpl_attn_fwd_variant(q, ldq, o, ldo, k_pages, v_pages, ldk, ldv, n_pages, page_rows, Lq, num_heads, softmax_scale, workspace,
+                               workspace_bytes, ATTN_AUTO, 0, stream);
 }
 
 int mmpl_attn_fwd(const void* q, int ldq, void* o, int ldo, const void* const* k_pages, const void* const* v_pages,

@@ -608,54 +608,56 @@ size_t mmpl_attention_split_ws_bytes() { return (size_t)256 * QB * 130 * sizeof(
 hipError_t mmpl_launch_attention(const AttnArgs& a, hipStream_t s) {
   if (a.Lq <= 0) return hipSuccess;
   if (a.n_pages <= 0 || a.n_pages > MMPL_MAX_PAGES || a.page_rows <= 0 || (a.ldq % 8) || (a.ldk % 8) || (a.ldv % 8) ||
-      (a.ldo % 4))
+      (a.ldo % 4) || a.variant < ATTN_AUTO || a.variant > ATTN_W64)
     return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<0>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_SMEM);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_SMEM);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  // Kernel choice.  Self-attention over cache pages -> the 64-rows-per-wave kernel (attn_w64.hip); the 8-tile text
+  // cross-attention stays on the lock-step kernel (its prologue is the shortest).  AttnArgs.variant (C ABI:
+  // mmpl_attn_fwd_variant) or, for A/B runs of a whole forward, MMPL_ATTN_V1=1 / MMPL_ATTN_PP=1 select another one.
+  static const bool env_v1 = getenv("MMPL_ATTN_V1") && atoi(getenv("MMPL_ATTN_V1"));
+  static const bool env_pp = getenv("MMPL_ATTN_PP") && atoi(getenv("MMPL_ATTN_PP"));
+  static const bool no_split = getenv("MMPL_ATTN_NOSPLIT") && atoi(getenv("MMPL_ATTN_NOSPLIT"));
+  int variant = a.variant;
+  if (variant == ATTN_AUTO) variant = a.cross || env_v1 ? ATTN_LOCKSTEP : env_pp ? ATTN_PINGPONG : ATTN_W64;
   const int n_qb = (a.Lq + QB - 1) / QB;
-  // self-attention over cache pages -> ping-pong kernel; the 8-tile text cross-attention stays on the lock-step kernel
-  // (its prologue is shorter).  MMPL_ATTN_V1=1 forces the lock-step kernel everywhere (A/B runs).
-  static const bool force_v1 = getenv("MMPL_ATTN_V1") && atoi(getenv("MMPL_ATTN_V1"));
-  if (a.cross) hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(n_qb * a.H), dim3(512), SMEM, s, a);
-  else if (force_v1) hipLaunchKernelGGL(attn_fwd_kernel<0>, dim3(n_qb * a.H), dim3(512), SMEM, s, a);
-  else {
-    // Tail round: with one block per CU and b = n_qb*H/8 query blocks per XCD (32 CUs), the last b mod 32 blocks of every
-    // XCD would run alone for a whole block time.  They are launched instead as `sp` blocks each over 1/sp of the KV tiles
-    // (fp32 partials in split_ws) followed by a small merge kernel, so the tail round lasts ~1/sp block times.
-    static int per_xcd = 0;
-    static const bool no_split = getenv("MMPL_ATTN_NOSPLIT") && atoi(getenv("MMPL_ATTN_NOSPLIT"));
-    if (!per_xcd) {
-      hipDeviceProp_t prop;
-      int dev = 0;
-      per_xcd = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount / 8 : 32;
-      if (per_xcd < 1) per_xcd = 32;
-    }
-    const int tiles = a.n_pages * ((a.page_rows + KVB - 1) / KVB);
-    int sp = 1, tb = 0, b = 0;
-    if (!no_split && a.split_ws && (a.H & 7) == 0) {
-      b = n_qb * (a.H / 8);
-      tb = b % per_xcd;
-      if (b > per_xcd && tb > 0 && per_xcd / tb >= 2) sp = per_xcd / tb > 4 ? 4 : per_xcd / tb;
-      if (tiles / sp < 8 || (size_t)8 * tb * sp * QB * 130 * sizeof(float) > a.split_ws_bytes) sp = 1;
-    }
-    if (sp == 1) {
-      hipLaunchKernelGGL(attn_pp_kernel<false>, dim3(n_qb * a.H), dim3(512), PP_SMEM, s, a, 0, 1);
-    } else {
-      hipLaunchKernelGGL(attn_pp_kernel<false>, dim3(8 * (b - tb)), dim3(512), PP_SMEM, s, a, 0, 1);
-      hipLaunchKernelGGL(attn_pp_kernel<true>, dim3(8 * tb * sp), dim3(512), PP_SMEM, s, a, b - tb, sp);
-      hipLaunchKernelGGL(attn_merge_kernel, dim3(8 * tb), dim3(256), 0, s, a, b - tb, sp, tb);
-    }
+  if (variant == ATTN_LOCKSTEP) {
+    const void* f = a.cross ? reinterpret_cast<const void*>(attn_fwd_kernel<1>) : reinterpret_cast<const void*>(attn_fwd_kernel<0>);
+    if (hipError_t e = mmpl_dyn_smem_once(f, SMEM); e != hipSuccess) return e;
+    if (a.cross) hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(n_qb * a.H), dim3(512), SMEM, s, a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<0>, dim3(n_qb * a.H), dim3(512), SMEM, s, a);
+    return hipGetLastError();
+  }
+  const bool w64 = variant == ATTN_W64;
+  if (hipError_t e = w64 ? mmpl_dyn_smem_once(mmpl_attention_w64_symbol(0), mmpl_attention_w64_smem())
+                         : mmpl_dyn_smem_once(reinterpret_cast<const void*>(attn_pp_kernel<false>), PP_SMEM);
+      e != hipSuccess)
+    return e;
+  if (hipError_t e = w64 ? mmpl_dyn_smem_once(mmpl_attention_w64_symbol(1), mmpl_attention_w64_smem())
+                         : mmpl_dyn_smem_once(reinterpret_cast<const void*>(attn_pp_kernel<true>), PP_SMEM);
+      e != hipSuccess)
+    return e;
+  auto run = [&](int blocks, int local_base, int sp, bool split) {
+    if (w64) mmpl_launch_attention_w64(a, blocks, local_base, sp, split, s);
+    else if (split) hipLaunchKernelGGL(attn_pp_kernel<true>, dim3(blocks), dim3(512), PP_SMEM, s, a, local_base, sp);
+    else hipLaunchKernelGGL(attn_pp_kernel<false>, dim3(blocks), dim3(512), PP_SMEM, s, a, local_base, sp);
+  };
+  // Tail round: with one block per CU and b = n_qb*H/8 query blocks per XCD (32 CUs), the last b mod 32 blocks of every
+  // XCD would run alone for a whole block time.  They are launched instead as `sp` blocks each over 1/sp of the KV tiles
+  // (fp32 partials in split_ws) followed by a small merge kernel, so the tail round lasts ~1/sp block times.
+  const int per_xcd = mmpl_cus_per_xcd();
+  const int tiles = a.n_pages * ((a.page_rows + KVB - 1) / KVB);
+  int sp = 1, tb = 0, b = 0;
+  if (!no_split && a.split_ws && (a.H & 7) == 0) {
+    b = n_qb * (a.H / 8);
+    tb = b % per_xcd;
+    if (b > per_xcd && tb > 0 && per_xcd / tb >= 2) sp = per_xcd / tb > 4 ? 4 : per_xcd / tb;
+    if (tiles / sp < 8 || (size_t)8 * tb * sp * QB * 130 * sizeof(float) > a.split_ws_bytes) sp = 1;
+  }
+  if (sp == 1) {
+    run(n_qb * a.H, 0, 1, false);
+  } else {
+    run(8 * (b - tb), 0, 1, false);
+    run(8 * tb * sp, b - tb, sp, true);
+    hipLaunchKernelGGL(attn_merge_kernel, dim3(8 * tb), dim3(256), 0, s, a, b - tb, sp, tb);
   }
   return hipGetLastError();
 }

@@ -542,14 +542,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 template <int EPI>
 hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
-  static bool attr_set = false;
   constexpr int smem = 2 * STAGE4;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_v6_kernel<EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v6_kernel<EPI>), smem); e != hipSuccess) return e;
   const int tiles = ((g.M + BM3 - 1) / BM3) * ((g.N + BN3 - 1) / BN3);
   GemmArgs g2 = g;
   g2.group = 4;
@@ -559,14 +553,8 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
 
 template <int EPI>
 hipError_t launch_v4(const GemmArgs& g, hipStream_t s) {
-  static bool attr_set = false;
   constexpr int smem = 2 * STAGE4;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_v4_kernel<EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v4_kernel<EPI>), smem); e != hipSuccess) return e;
   const int tiles = ((g.M + BM3 - 1) / BM3) * ((g.N + BN3 - 1) / BN3);
   GemmArgs g2 = g;
   g2.group = 4;
@@ -576,14 +564,8 @@ hipError_t launch_v4(const GemmArgs& g, hipStream_t s) {
 
 template <int EPI>
 hipError_t launch_v2(const GemmArgs& g, hipStream_t s) {
-  static bool attr_set = false;
   constexpr int smem = NSTAGE2 * STAGE2;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_v2_kernel<EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v2_kernel<EPI>), smem); e != hipSuccess) return e;
   const int tiles = ((g.M + BM2 - 1) / BM2) * ((g.N + BN2 - 1) / BN2);
   hipLaunchKernelGGL(gemm_bf16_v2_kernel<EPI>, dim3(tiles), dim3(512), smem, s, g);
   return hipGetLastError();
@@ -598,14 +580,8 @@ hipError_t launch(const GemmArgs& g, hipStream_t s) {
   if (big && !env_v4 && (long long)g.M * g.lda < (1ll << 31) && (long long)g.N * g.ldw < (1ll << 31)) return launch_v6<EPI>(g, s);
   if (big) return launch_v4<EPI>(g, s);
   if (g.batch <= 1 && g.M >= 1024 && g.N >= 128 && g.K >= 128 && !env_v1) return launch_v2<EPI>(g, s);
-  static bool attr_set = false;
   constexpr int smem = 4 * TILE_BYTES;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_kernel<EPI>), smem); e != hipSuccess) return e;
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
   hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(tiles, g.batch > 1 ? g.batch : 1), dim3(256), smem, s, g);
   return hipGetLastError();

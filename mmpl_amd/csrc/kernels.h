@@ -4,6 +4,10 @@
 #include <stdint.h>
 #include "common.h"
 
+// ---------------------------------------------------------------- per-device launcher state (device_state.hip)
+hipError_t mmpl_dyn_smem_once(const void* func, int bytes);   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel)
+int mmpl_cus_per_xcd();                                       // CUs / 8 of the current device
+
 // ---------------------------------------------------------------- GEMM (gemm.hip)
 enum GemmEpi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_SILU = 2, EPI_GATE_RES = 3, EPI_RES = 4, EPI_F32_SCALE = 5,
                EPI_BIAS_VPAGES = 6 };   // bias; columns >= v_col0 go to per-frame pages instead of C (the V third of the fused qkv)
@@ -40,7 +44,13 @@ struct AttnArgs {
   float scale;                     // softmax scale (1/sqrt(128))
   int cross;                       // 1: text cross-attention launch (symbol tag only)
   float* split_ws; size_t split_ws_bytes;   // optional scratch for the split-KV tail round (nullptr: never split)
+  int variant;                     // MMPL_ATTN_* kernel selector (0 = auto)
 };
+enum { ATTN_AUTO = 0, ATTN_LOCKSTEP = 1, ATTN_PINGPONG = 2, ATTN_W64 = 3 };
+// attn_w64.hip (4 waves x 64 query rows, one wave per SIMD)
+int mmpl_attention_w64_smem();
+const void* mmpl_attention_w64_symbol(int split);
+void mmpl_launch_attention_w64(const AttnArgs& a, int blocks, int local_base, int sp, bool split, hipStream_t s);
 size_t mmpl_attention_split_ws_bytes();     // upper bound of what a launch can use
 hipError_t mmpl_launch_attention(const AttnArgs& a, hipStream_t s);
 
