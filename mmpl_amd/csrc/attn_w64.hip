@@ -23,6 +23,8 @@
 // rare path.  The common path just sums the tile's p; if any lane's partial sum is not <= 2^30 (first tile: m_ref = -inf ->
 // +inf) the tile is redone on the slow path: exact row max, m_ref = max(m_ref, max), O and l rescaled, p recomputed.  So p <= 2^30
 // always, l >= 1 after the first tile, and the result is the exact softmax up to rounding (fp32 exponent range is never at risk).
+#include <stdlib.h>
+
 #include <type_traits>
 #include <utility>
 
@@ -31,8 +33,7 @@
 
 namespace {
 
-constexpr int QB = 256, KVB = 64, RING = 4, TILE = KVB * 256;       // K ring [0, RING*TILE), V ring behind it
-constexpr int W64_SMEM = 2 * RING * TILE;                             // 131072
+constexpr int QB = 256, KVB = 64, TILE = KVB * 256;                   // K ring [0, RING*TILE), V ring behind it
 constexpr float L_BOUND = 1073741824.f;                               // 2^30
 
 template <int I> using ic = std::integral_constant<int, I>;
@@ -165,7 +166,9 @@ template <int X> MMPL_DEV void sm_finish(W64& w, float c) {
   w.l[X] += lt;
 }
 
-template <bool SPLIT>
+// RING: tiles per LDS ring = how far ahead the LDS-DMA runs (K(j+RING), V(j+RING-1) are issued during tile j).
+// ABL (dev builds only): timing ablations, results are garbage -- 1 no LDS-DMA in the loop, 2 no softmax, 4 no fragment reads.
+template <int RING, int ABL, bool SPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_w64_kernel(AttnArgs a, int local_base, int sp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -311,20 +314,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       constexpr int g = decltype(gi)::value;
       if constexpr (g < 16) { if constexpr (QK) mfma_qk<0, g>(w); }
       else { if constexpr (PV) mfma_pv<0, g - 16>(w); }
-      if constexpr (PV) sm_gap<1, g>(w, c);
-      if constexpr (PV && g == 0) lds_v<15>(vaddr[3]);
+      if constexpr (PV && !(ABL & 2)) sm_gap<1, g>(w, c);
+      if constexpr (PV && !(ABL & 4) && g == 0) lds_v<15>(vaddr[3]);
       if constexpr (g == 3) {
         if constexpr (QK) asm volatile("s_waitcnt vmcnt(%c0) lgkmcnt(0)\n\ts_barrier" ::"i"(8 * (RING - 2)) : "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
-      if constexpr (QK && g >= 5 && g <= 11 && (g & 1)) issue_k(ic<(g - 5) / 2>{});
-      if constexpr (QK && g >= 13 && g <= 19 && (g & 1)) issue_v(ic<(g - 13) / 2>{});
+      if constexpr (QK && !(ABL & 1) && g >= 5 && g <= 11 && (g & 1)) issue_k(ic<(g - 5) / 2>{});
+      if constexpr (QK && !(ABL & 1) && g >= 13 && g <= 19 && (g & 1)) issue_v(ic<(g - 13) / 2>{});
       if constexpr (QK && g == 21) {
         advance(ck, a.k_pages, a.ldk, kslot, 0);
         advance(cv, a.v_pages, a.ldv, vslot, RING * TILE);
       }
     });
-    if constexpr (PV) sm_finish<1>(w, c);
+    if constexpr (PV && !(ABL & 2)) sm_finish<1>(w, c);
   };
   // ---- phase B(j): MFMAs of query block B, softmax of query block A, fragment reads of K(j+1) and V(j)
   auto phase_b = [&](auto has_qk, auto has_pv) {
@@ -343,19 +346,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if constexpr (g < 16) { if constexpr (QK) mfma_qk<1, g>(w); }
       else { if constexpr (PV) mfma_pv<1, g - 16>(w); }
       if constexpr (QK) {
-        sm_gap<0, g>(w, c);
-        if constexpr (g >= 1 && g <= 16) {
+        if constexpr (!(ABL & 2)) sm_gap<0, g>(w, c);
+        if constexpr (!(ABL & 4) && g >= 1 && g <= 16) {
           constexpr int f = g - 1;                       // K(j) fragment f was last read by MFMA f of this phase
           if constexpr ((f & 1) == 0 && f > 0) lds_k_next<f, (32 * (f >> 1)) ^ (32 * ((f >> 1) - 1))>(w, kaddr);
           else lds_k<f>(w, kaddr);
         }
         if constexpr (g >= 13 && g <= 15) vaddr[g - 12] = v_xor<64 * (g - 12)>(vaddr[0]);
         if constexpr (g == 22) asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");     // the 16 K reads are older than the 10 V reads since
-        if constexpr (g >= 17) lds_v<g - 17>(vaddr[(g - 17) & 3]);
+        if constexpr (!(ABL & 4) && g >= 17) lds_v<g - 17>(vaddr[(g - 17) & 3]);
       }
     });
     if constexpr (QK) {
-      sm_finish<0>(w, c);
+      if constexpr (!(ABL & 2)) sm_finish<0>(w, c);
       rk += TILE; if (rk >= RING * TILE) rk = 0;
       rv += TILE; if (rv >= RING * TILE) rv = 0;
     }
@@ -416,11 +419,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 }  // namespace
 
-int mmpl_attention_w64_smem() { return W64_SMEM; }
-const void* mmpl_attention_w64_symbol(int split) {
-  return split ? reinterpret_cast<const void*>(attn_w64_kernel<true>) : reinterpret_cast<const void*>(attn_w64_kernel<false>);
+namespace {
+template <int RING, int ABL>
+const void* w64_sym(int split) {
+  return split ? reinterpret_cast<const void*>(attn_w64_kernel<RING, ABL, true>) : reinterpret_cast<const void*>(attn_w64_kernel<RING, ABL, false>);
 }
+template <int RING, int ABL>
+void w64_launch(const AttnArgs& a, int blocks, int local_base, int sp, bool split, hipStream_t s) {
+  if (split) hipLaunchKernelGGL((attn_w64_kernel<RING, ABL, true>), dim3(blocks), dim3(256), 2 * RING * TILE, s, a, local_base, sp);
+  else hipLaunchKernelGGL((attn_w64_kernel<RING, ABL, false>), dim3(blocks), dim3(256), 2 * RING * TILE, s, a, local_base, sp);
+}
+// dev knobs, read once per process: MMPL_W64_RING (2..4), MMPL_W64_ABL (timing ablations, garbage results)
+int w64_ring() { static const int r = getenv("MMPL_W64_RING") ? atoi(getenv("MMPL_W64_RING")) : 4; return r; }
+int w64_abl() { static const int r = getenv("MMPL_W64_ABL") ? atoi(getenv("MMPL_W64_ABL")) : 0; return r; }
+#define W64_DISPATCH(expr)                                                   \
+  do {                                                                       \
+    const int r_ = w64_ring(), b_ = w64_abl();                               \
+    if (b_ == 1) { constexpr int RING = 2, ABL = 1; expr; }                  \
+    else if (b_ == 2) { constexpr int RING = 2, ABL = 2; expr; }             \
+    else if (b_ == 4) { constexpr int RING = 2, ABL = 4; expr; }             \
+    else if (b_ == 6) { constexpr int RING = 2, ABL = 6; expr; }             \
+    else if (b_ == 7) { constexpr int RING = 2, ABL = 7; expr; }             \
+    else if (r_ == 2) { constexpr int RING = 2, ABL = 0; expr; }             \
+    else if (r_ == 3) { constexpr int RING = 3, ABL = 0; expr; }             \
+    else { constexpr int RING = 4, ABL = 0; expr; }                          \
+  } while (0)
+}  // namespace
+
+int mmpl_attention_w64_smem() { int v = 0; W64_DISPATCH(v = 2 * RING * TILE; (void)ABL); return v; }
+const void* mmpl_attention_w64_symbol(int split) { const void* p = nullptr; W64_DISPATCH(p = (w64_sym<RING, ABL>(split))); return p; }
 void mmpl_launch_attention_w64(const AttnArgs& a, int blocks, int local_base, int sp, bool split, hipStream_t s) {
-  if (split) hipLaunchKernelGGL(attn_w64_kernel<true>, dim3(blocks), dim3(256), W64_SMEM, s, a, local_base, sp);
-  else hipLaunchKernelGGL(attn_w64_kernel<false>, dim3(blocks), dim3(256), W64_SMEM, s, a, local_base, sp);
+  W64_DISPATCH((w64_launch<RING, ABL>(a, blocks, local_base, sp, split, s)));
 }

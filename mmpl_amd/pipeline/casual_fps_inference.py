@@ -44,7 +44,7 @@ class CausalFPSInferencePipeline(torch.nn.Module):
         self.generator_cond = WanFPSWrapper(**getattr(args, "model_kwargs", {}), is_causal=True, geometry=self.geometry,
                                             device=device_cond) if generator is None else generator
         self.generator_cond.model.num_frame_per_block = 1
-        self.text_encoder = WanTextEncoder() if text_encoder is None else text_encoder
+        self.text_encoder = WanTextEncoder(device=device_cond) if text_encoder is None else text_encoder
         self.vae = WanVAEWrapper(geometry=self.geometry, device=device_cond) if vae is None else vae
 
         self.num_train_timesteps = args.num_train_timestep

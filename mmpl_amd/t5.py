@@ -33,7 +33,8 @@ class T5Engine:
                                     num_heads=cfg["num_heads"], num_layers=cfg["num_layers"], num_buckets=cfg["num_buckets"],
                                     text_len=text_len, eps=1e-6)
         h = C.c_void_p()
-        _lib.check(self._lib.mmpl_t5_create(C.byref(self._c), C.byref(h)), "mmpl_t5_create")
+        with torch.cuda.device(self.device):          # the handle, its stream and every launch belong to THIS device
+            _lib.check(self._lib.mmpl_t5_create(C.byref(self._c), C.byref(h)), "mmpl_t5_create")
         self._h = h
         self._bucket = relative_position_buckets(text_len, cfg["num_buckets"]).to(self.device)
         self._weights: List[torch.Tensor] = []
@@ -72,7 +73,8 @@ class T5Engine:
         ids = ids.to(device=self.device, dtype=torch.int32).contiguous()
         mask = mask.to(device=self.device, dtype=torch.int32).contiguous()
         out = torch.empty(B, L, self.cfg["dim"], dtype=torch.bfloat16, device=self.device)
-        for b in range(B):
-            _lib.check(self._lib.mmpl_t5_encode(self._h, _lib.ptr(ids[b]), _lib.ptr(mask[b]), _lib.ptr(self._bucket), _lib.ptr(out[b]),
-                                                _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr()), "mmpl_t5_encode")
+        with torch.cuda.device(self.device):          # _lib.stream_ptr() = the current stream of the current device
+            for b in range(B):
+                _lib.check(self._lib.mmpl_t5_encode(self._h, _lib.ptr(ids[b]), _lib.ptr(mask[b]), _lib.ptr(self._bucket), _lib.ptr(out[b]),
+                                                    _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr()), "mmpl_t5_encode")
         return out

@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import json
 from pathlib import Path
+from typing import NamedTuple
 
 from PIL import Image
 from torch.utils.data import Dataset
@@ -46,42 +47,61 @@ class TextDataset(Dataset):
         return item
 
 
+def _find_manifest(root: Path) -> Path:
+    """The single ``target_crop_info_<ratio>.json`` of an image-prompt folder."""
+    found = sorted(root.glob("target_crop_info_*.json"))
+    if len(found) != 1:
+        kind = FileNotFoundError if not found else ValueError
+        raise kind(f"{root}: expected exactly one target_crop_info_*.json manifest, found {len(found)}")
+    return found[0]
+
+
+class _ImageRecord(NamedTuple):
+    path: Path
+    caption: str
+    bbox: list
+    ratio: str
+    kind: str
+    size: tuple
+
+
 class TextImagePairDataset(Dataset):
-    """data_dir holds ONE ``target_crop_info_<ratio>.json`` (list of {file_name, caption, target_crop{target_bbox,
-    target_ratio}, type, origin_width, origin_height}) and the image folder ``<ratio>/``."""
+    """Image + caption pairs for the I2V entry scripts (interface of MMPL_t2v/utils/dataset.py:127-215: same constructor
+    arguments and item keys).  Folder layout: ``<data_dir>/target_crop_info_<ratio>.json`` -- a JSON list of
+    {file_name, caption, target_crop: {target_bbox, target_ratio}, type, origin_width, origin_height} -- next to the image
+    folder ``<data_dir>/<ratio>/``.  Every manifest row is resolved to a record up front (a missing image fails at
+    construction, not at item time); ``eval_first_n`` keeps a prefix, ``pad_to_multiple_of`` repeats the last record so that
+    the length divides evenly across ranks (``pre_pad_len`` is the un-padded length)."""
 
     def __init__(self, data_dir, transform=None, eval_first_n=-1, pad_to_multiple_of=None):
+        root = Path(data_dir)
+        manifest = _find_manifest(root)
+        ratio = manifest.stem[len("target_crop_info_"):]
+        folder = root / ratio
+        if not folder.is_dir():
+            raise FileNotFoundError(f"{folder}: image folder named by {manifest.name} is missing")
+        rows = json.loads(manifest.read_text())
+        if eval_first_n >= 0:
+            rows = rows[:eval_first_n]
+        records = [_ImageRecord(folder / r["file_name"], r["caption"], r["target_crop"]["target_bbox"],
+                                r["target_crop"]["target_ratio"], r["type"], (r["origin_width"], r["origin_height"])) for r in rows]
+        absent = [str(rec.path) for rec in records if not rec.path.is_file()]
+        if absent:
+            raise FileNotFoundError(f"{len(absent)} image(s) listed in {manifest.name} do not exist, first: {absent[0]}")
         self.transform = transform
-        data_dir = Path(data_dir)
-        metadata_files = list(data_dir.glob("target_crop_info_*.json"))
-        if not metadata_files:
-            raise FileNotFoundError(f"No metadata file found in {data_dir}")
-        if len(metadata_files) > 1:
-            raise ValueError(f"Multiple metadata files found in {data_dir}")
-        metadata_path = metadata_files[0]
-        self.image_dir = data_dir / metadata_path.stem.split("_")[-1]
-        if not self.image_dir.exists():
-            raise FileNotFoundError(f"Image directory not found: {self.image_dir}")
-        with open(metadata_path, "r") as f:
-            self.metadata = json.load(f)
-        if eval_first_n != -1:
-            self.metadata = self.metadata[:eval_first_n]
-        for item in self.metadata:
-            if not (self.image_dir / item["file_name"]).exists():
-                raise FileNotFoundError(f"Image not found: {self.image_dir / item['file_name']}")
-        self.dummy_prompt = "DUMMY PROMPT"
-        self.pre_pad_len = len(self.metadata)
-        if pad_to_multiple_of is not None and len(self.metadata) % pad_to_multiple_of != 0:
-            self.metadata += [self.metadata[-1]] * (pad_to_multiple_of - len(self.metadata) % pad_to_multiple_of)
+        self.image_dir = folder
+        self.pre_pad_len = len(records)
+        shortfall = -len(records) % pad_to_multiple_of if pad_to_multiple_of else 0
+        self._records = records + records[-1:] * shortfall
 
     def __len__(self):
-        return len(self.metadata)
+        return len(self._records)
 
     def __getitem__(self, idx):
-        item = self.metadata[idx]
-        image = Image.open(self.image_dir / item["file_name"]).convert("RGB")
-        if self.transform:
+        rec = self._records[idx]
+        with Image.open(rec.path) as fh:
+            image = fh.convert("RGB")
+        if self.transform is not None:
             image = self.transform(image)
-        return {"image": image, "prompts": item["caption"], "target_bbox": item["target_crop"]["target_bbox"],
-                "target_ratio": item["target_crop"]["target_ratio"], "type": item["type"],
-                "origin_size": (item["origin_width"], item["origin_height"]), "idx": idx}
+        return dict(image=image, prompts=rec.caption, target_bbox=rec.bbox, target_ratio=rec.ratio, type=rec.kind,
+                    origin_size=rec.size, idx=idx)

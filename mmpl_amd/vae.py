@@ -19,7 +19,8 @@ class VaeEngine:
         self.device = torch.device(device)
         self._lib = _lib.load()
         h = C.c_void_p()
-        _lib.check(self._lib.mmpl_vae_create(lat_h, lat_w, C.byref(h)), "mmpl_vae_create")
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.mmpl_vae_create(lat_h, lat_w, C.byref(h)), "mmpl_vae_create")
         self._h = h
         self._weights: List[torch.Tensor] = []
         self._ws: Dict[int, torch.Tensor] = {}
@@ -94,8 +95,9 @@ class VaeEngine:
         out = torch.empty(1 + 4 * (F - 1), 3, 8 * self.lat_h, 8 * self.lat_w, dtype=torch.float32, device=self.device)
         ws = self._workspace(0)
         m, inv = self._scales(mean, std)
-        _lib.check(self._lib.mmpl_vae_decode(self._h, _lib.ptr(z), F, m, inv, _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
-                   "mmpl_vae_decode")
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.mmpl_vae_decode(self._h, _lib.ptr(z), F, m, inv, _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+                       "mmpl_vae_decode")
         return out
 
     def encode(self, pixel: torch.Tensor, mean, std) -> torch.Tensor:
@@ -106,6 +108,7 @@ class VaeEngine:
         out = torch.empty(1 + (T - 1) // 4, 16, self.lat_h, self.lat_w, dtype=torch.float32, device=self.device)
         ws = self._workspace(1)
         m, inv = self._scales(mean, std)
-        _lib.check(self._lib.mmpl_vae_encode(self._h, _lib.ptr(x), T, m, inv, _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
-                   "mmpl_vae_encode")
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.mmpl_vae_encode(self._h, _lib.ptr(x), T, m, inv, _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+                       "mmpl_vae_encode")
         return out

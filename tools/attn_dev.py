@@ -103,11 +103,13 @@ def timeit(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
-def bench(variants, iters=3, rounds=3):
+def bench(variants, iters=3, rounds=3, stages=("s0", "s1", "s2", "s3")):
     H, S, d = 40, 3600, 5120
     kc = torch.randn(21 * S, d, device=dev).to(BF)
     vc = torch.randn(21 * S, d, device=dev).to(BF)
     for name, nq, npg in (("s0", 2, 2), ("s1", 7, 9), ("s2", 6, 13), ("s3", 6, 21)):
+        if name not in stages:
+            continue
         Lq = nq * S
         q = torch.randn(Lq, 3 * d, device=dev).to(BF)
         kp = (C.c_void_p * npg)(*[kc[i * S:].data_ptr() for i in range(npg)])
@@ -129,7 +131,8 @@ def bench(variants, iters=3, rounds=3):
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "check"
-    variants = [int(x) for x in sys.argv[2:]] or [2, 3]
+    variants = [int(x) for x in sys.argv[2:] if x.isdigit()] or [2, 3]
+    stages = [x.split("=")[1].split(",") for x in sys.argv[2:] if x.startswith("stages=")]
     if what == "check":
         sys.exit(1 if check(variants) else 0)
-    bench(variants)
+    bench(variants, stages=stages[0] if stages else ("s0", "s1", "s2", "s3"))
