@@ -37,7 +37,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "mmpl_hip.h"))
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     jobs = []

@@ -6,23 +6,27 @@
 //
 // Register plan (per lane).  Accumulator half, named literally in the asm below and never seen by the compiler:
 //     a[0:63] O_A   a[64:127] O_B   (4 d-blocks x 16 fp32 each)
-//     a[128:159] Q_A   a[160:191] Q_B   (8 hd chunks x 4 regs: B operand of S^T = K.Q^T)
+//     a[128:159] Q_A   a[160:191] Q_B   (8 hd chunks x 4 regs: B operand of S^T = K.Q^T; PRESCALED by scale*log2(e))
 //     a[192:255] V fragments of one KV tile (16 x 4 regs, written straight from LDS by ds_read_b64_tr_b16)
-// Architectural half (compiler-allocated, every hot instruction is an `asm volatile` so program order == source order):
+// Architectural half (compiler-allocated; every hot instruction is an `asm volatile`, so program order == source order):
 //     S_A, S_B (2 x 32 fp32), P_A, P_B (2 x 16 packed bf16 pairs), the 16 K fragments of one tile (64), softmax state.
 //
 // Schedule.  The two query blocks run HALF A TILE APART; per KV tile j two phases of 32 MFMAs, one barrier per tile:
-//     A(j): MFMA  S_A(j) = K(j).Q_A [16]  then  O_A += V(j-1).P_A(j-1) [16]      VALU: softmax of S_B(j-1) -> P_B(j-1)
-//           LDS-DMA of tiles j+4 (K) / j+3 (V), 8 pieces per wave, after the barrier
-//     B(j): MFMA  S_B(j) = K(j).Q_B [16]  then  O_B += V(j-1).P_B(j-1) [16]      VALU: softmax of S_A(j)   -> P_A(j)
-//           LDS reads: K(j+1) fragment i right behind the last MFMA that used K(j) fragment i, V(j) likewise
-// so each accumulator is finished 16 MFMAs (>= 512 cycles) before the VALU touches it and each P a phase before its MFMA, and
-// every gap between two MFMAs carries <= 5 other instructions (MI355X_MICROARCH.md: a 32x32x16 MFMA hides ~5 issues).
+//     A(j): S_A(j) = K(j).Q_A [16 MFMAs]  then  O_A += V(j-1).P_A(j-1) [16]     + LDS-DMA of K(j+4) / V(j+2), 8 pieces per wave
+//     B(j): S_B(j) = K(j).Q_B [16]        then  O_B += V(j-1).P_B(j-1) [16]     + fragment reads of K(j+1) and V(j), each right
+//                                                                                  behind the last MFMA that used its register
+// Everything that is not an MFMA is placed by tools/gen_attn_w64.py (attn_w64_sched.inc) into the gaps between them, <= ~5
+// issue slots per gap (MI355X_MICROARCH.md: that is what one 32x32x16 MFMA hides from the wave that issued it): the softmax
+// of S_B(j-1) streams through A(j) and the head of B(j), the softmax of S_A(j) through the tail of A(j) and B(j), so each
+// accumulator is finished >= 2 MFMAs before the VALU touches it and each P >= 2 gaps before its MFMA.
 //
-// Softmax without a row max on the common path: p = exp2(s*c - m_ref*c) against a per-row reference m_ref that only moves on a
-// rare path.  The common path just sums the tile's p; if any lane's partial sum is not <= 2^30 (first tile: m_ref = -inf ->
-// +inf) the tile is redone on the slow path: exact row max, m_ref = max(m_ref, max), O and l rescaled, p recomputed.  So p <= 2^30
-// always, l >= 1 after the first tile, and the result is the exact softmax up to rounding (fp32 exponent range is never at risk).
+// Softmax without a row max on the common path.  Q is prescaled, so S is in log2 units and p = exp2(S - m_ref) against a per-row
+// reference m_ref.  FAST mode: m_ref = 0 for every row of the wave (p = exp2(S): one v_exp, one add and half a cvt_pk per
+// score); entered when the first tile's row maxima are all within +-2^6.  GENERAL mode: p = exp2(S - m_ref) (one more VALU
+// per score).  Either way a tile is accepted when every lane's partial row sum is <= a bound (2^80 / 2^30); otherwise it is
+// redone on a slow path (exact row max, m_ref = max(m_ref, max), O and l rescaled through v_accvgpr moves, p recomputed) and
+// the wave continues in GENERAL mode.  So p never overflows, l >= 2^-64 after the first tile, and the result is the exact
+// softmax up to rounding for any input (tests: spiked scores far beyond both bounds).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -33,8 +37,12 @@
 
 namespace {
 
-constexpr int QB = 256, KVB = 64, TILE = KVB * 256;                   // K ring [0, RING*TILE), V ring behind it
-constexpr float L_BOUND = 1073741824.f;                               // 2^30
+constexpr int QB = 256, KVB = 64, TILE = KVB * 256, RING = 4;         // K ring [0, 64 KiB), V ring [64 KiB, 128 KiB)
+constexpr int W64_SMEM = 2 * RING * TILE;
+constexpr float BOUND_FAST = 1.2089258e24f;                            // 2^80
+constexpr float BOUND_GEN = 1073741824.f;                              // 2^30
+constexpr float FIRST_RANGE = 64.f;
+constexpr int DMA_BIAS = 4096;                                         // keeps "row offset - LDS piece offset" non-negative
 
 template <int I> using ic = std::integral_constant<int, I>;
 template <class F, int... I> MMPL_DEV void sfor_(F&& f, std::integer_sequence<int, I...>) { (f(ic<I>{}), ...); }
@@ -48,129 +56,227 @@ template <int N, class F> MMPL_DEV void sfor(F&& f) { sfor_(f, std::make_integer
 
 constexpr int AO = 0, AQ = 128, AV = 192;      // accumulator-file map
 
-struct W64 {
-  f32x16 S[2][2];      // [query block][kv half]
-  u32x4 P[2][4];       // [query block][16-row kv step]: 8 bf16 = B operand of O^T += V^T.P^T
-  bf16x8 kf[16];       // K fragments of one tile: i = 2*chunk + half
-  float l[2], mref[2], nmc[2];
-  float la, lb, p0, p1;
+// All state of a wave.  Passed by reference through always-inlined members, so every field ends up in a register (VGPR or,
+// when provably wave-uniform, SGPR); arrays are only ever indexed with compile-time constants.
+struct Ctx {
+  // ---- vector state
+  f32x16 S[2][2];        // [query block][kv half]
+  u32x4 P[2][4];         // [query block][16-row kv step]: 8 bf16 = B operand of O^T += V^T.P^T
+  bf16x8 kf[16];         // K fragments of one tile: i = 2*chunk + half
+  float l[2], mref[2];   // running row sum (this lane's 32 kv columns of every tile) and reference (log2 units)
+  float la[2], lb[2];    // the tile's partial sums (even / odd register of each pair)
+  float t[2][2][2];      // exp results in flight: [stream][pair parity][element]
+  uint32_t dko[4], dvo[4];   // per-piece LDS-DMA source offsets of the tile under the K / V cursor
+  uint32_t kbase, vbase, kaddr, vaddr[4];
+  int hi;
+  // ---- wave-uniform state
+  const bf16_t* const* k_pages; const bf16_t* const* v_pages;
+  int ldk, ldv, page_rows, head, T;
+  const bf16_t* kptr; const bf16_t* vptr;      // cursor tile's first row, this head, minus DMA_BIAS bytes
+  int krow0, kpg, kt, vrow0, vpg, vt;          // cursors: row within page, page, tile index within the block
+  uint32_t kslot, vslot;                       // LDS address of this wave's piece 0 in the slot the cursor tile goes to
+  uint32_t rk, rv;                             // ring offsets of the tiles the next B phase reads (K(j+1), V(j))
+  int crow[2];                                 // first kv row (within its page) of the tile each stream is at
+  int first[2];                                // stream has not finished its first tile yet
+  int gen;                                     // wave is in GENERAL mode
+  int prow, drow, dchunk;
+
+  // ---------------------------------------------------------------- MFMAs
+  template <int X, int G> MMPL_DEV void mfma_qk() {      // S_X[h] (+)= K frag G . Q_X[chunk]
+    constexpr int c = G >> 1, h = G & 1, qa = AQ + 32 * X + 4 * c;
+    if constexpr (c == 0)
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(S[X][h]) : "v"(kf[G]), "i"(qa), "i"(qa + 3));
+    else
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(S[X][h]) : "v"(kf[G]), "i"(qa), "i"(qa + 3));
+  }
+  template <int X, int G> MMPL_DEV void mfma_pv() {      // O_X[nb] += V frag G . P_X[ks]
+    constexpr int ks = G >> 2, nb = G & 3, oa = AO + 64 * X + 16 * nb, va = AV + 4 * G;
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], a[%c2:%c3], %4, a[%c0:%c1]" ::"i"(oa), "i"(oa + 15), "i"(va), "i"(va + 3),
+                 "v"(P[X][ks]));
+  }
+  // ---------------------------------------------------------------- LDS fragment reads
+  MMPL_DEV void addr_k() { asm volatile("v_add_u32 %0, %1, %2" : "=v"(kaddr) : "s"(rk), "v"(kbase)); }
+  MMPL_DEV void addr_v() {
+    asm volatile("v_add_u32 %0, %4, %5\n\tv_xor_b32 %1, 64, %0\n\tv_xor_b32 %2, 0x80, %0\n\tv_xor_b32 %3, 0xc0, %0"
+                 : "=&v"(vaddr[0]), "=&v"(vaddr[1]), "=&v"(vaddr[2]), "=&v"(vaddr[3]) : "s"(rv), "v"(vbase));
+  }
+  template <int G> MMPL_DEV void lds_k() {               // fragment G = (chunk, half); the chunk enters the address by XOR
+    constexpr int off = (G & 1) * 32 * 256, cs = G >> 1;
+    if constexpr ((G & 1) == 0 && G > 0)
+      asm volatile("v_xor_b32 %1, %2, %1\n\tds_read_b128 %0, %1 offset:%c3" : "=v"(kf[G]), "+v"(kaddr) : "i"((32 * cs) ^ (32 * (cs - 1))), "i"(off));
+    else
+      asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(kf[G]) : "v"(kaddr), "i"(off));
+  }
+  template <int G> MMPL_DEV void lds_v() {               // fragment G = (ks, nb) -> a[192 + 4G ..]
+    constexpr int va = AV + 4 * G, off = (G >> 2) * 16 * 256;
+    asm volatile("ds_read_b64_tr_b16 a[%c1:%c2], %0 offset:%c3\n\tds_read_b64_tr_b16 a[%c4:%c5], %0 offset:%c6" ::"v"(vaddr[G & 3]),
+                 "i"(va), "i"(va + 1), "i"(off), "i"(va + 2), "i"(va + 3), "i"(off + 8 * 256));
+  }
+  template <int N> MMPL_DEV void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%c0)" ::"i"(N) : "memory"); }
+  MMPL_DEV void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+  // K(j+1) and V(j) (DMA events j-3 and j-2) have landed when at most the 8 pieces of event j-1 are outstanding; all of this
+  // wave's fragment reads of the slots event j is about to overwrite are complete (lgkmcnt 0)
+  MMPL_DEV void barrier() { asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+  // ---------------------------------------------------------------- LDS-DMA (event j = { K(j+4), V(j+2) })
+  // A piece = 4 rows x 256 B = one global_load_lds_dwordx4.  Wave w moves pieces 4w..4w+3 of a tile; M0 (the LDS destination
+  // of piece 4w) is written once per tile and the instruction offset -- which the hardware adds to BOTH addresses -- steps
+  // the LDS side by 1 KiB per piece; the per-piece source offsets are pre-compensated (- 1024 k + DMA_BIAS, bias taken out of
+  // the base pointer).  Nothing the compiler emits in this kernel touches M0 (audited in the .s: no other m0 write).
+  template <int K> MMPL_DEV void dma_k() {
+    if constexpr (K == 0)
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(dko[0]), "s"(kptr), "s"(kslot) : "memory");
+    else
+      asm volatile("global_load_lds_dwordx4 %0, %1 offset:%c2" ::"v"(dko[K]), "s"(kptr), "i"(1024 * K) : "memory");
+  }
+  template <int K> MMPL_DEV void dma_v() {
+    if constexpr (K == 0)
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(dvo[0]), "s"(vptr), "s"(vslot) : "memory");
+    else
+      asm volatile("global_load_lds_dwordx4 %0, %1 offset:%c2" ::"v"(dvo[K]), "s"(vptr), "i"(1024 * K) : "memory");
+  }
+  // source offsets of the four pieces for a tile with `lim` + 1 valid rows (63: full tile; less: a page's ragged last tile,
+  // rows clamped to the last valid one and masked in the softmax).  The bank swizzle is keyed on the LDS row, not the source row.
+  MMPL_DEV void set_k_offsets(int lim) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      dko[k] = (uint32_t)(min(prow + 4 * k, lim) * ldk + ((dchunk ^ ((prow + 4 * k) & 15)) << 3)) * 2u + (DMA_BIAS - 1024 * k);
+  }
+  MMPL_DEV void set_v_offsets(int lim) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      dvo[k] = (uint32_t)(min(prow + 4 * k, lim) * ldv + ((dchunk ^ (drow << 2)) << 3)) * 2u + (DMA_BIAS - 1024 * k);
+  }
+  // Cursors stop on the block's last tile (it is simply re-fetched), so every event issues exactly 8 pieces and the counted
+  // waits never change.
+  MMPL_DEV void advance_k() {
+    kslot = (kslot + TILE) & (RING * TILE - 1);
+    if (kt + 1 < T) {
+      ++kt;
+      const bool was_ragged = krow0 + KVB > page_rows;
+      krow0 += KVB;
+      kptr += (size_t)KVB * ldk;
+      if (krow0 >= page_rows) {
+        krow0 = 0;
+        ++kpg;
+        kptr = k_pages[kpg] + head * 128 - DMA_BIAS / 2;
+      }
+      if (was_ragged || krow0 + KVB > page_rows) set_k_offsets(min(KVB - 1, page_rows - 1 - krow0));
+    }
+    asm volatile("" : "+s"(kptr));
+  }
+  MMPL_DEV void advance_v() {
+    vslot = RING * TILE + ((vslot + TILE) & (RING * TILE - 1));
+    if (vt + 1 < T) {
+      ++vt;
+      const bool was_ragged = vrow0 + KVB > page_rows;
+      vrow0 += KVB;
+      vptr += (size_t)KVB * ldv;
+      if (vrow0 >= page_rows) {
+        vrow0 = 0;
+        ++vpg;
+        vptr = v_pages[vpg] + head * 128 - DMA_BIAS / 2;
+      }
+      if (was_ragged || vrow0 + KVB > page_rows) set_v_offsets(min(KVB - 1, page_rows - 1 - vrow0));
+    }
+    asm volatile("" : "+s"(vptr));
+  }
+  MMPL_DEV void rotate() {                               // end of B(j): the next B phase reads the next ring slots
+    rk = (rk + TILE) & (RING * TILE - 1);
+    rv = (rv + TILE) & (RING * TILE - 1);
+  }
+
+  // ---------------------------------------------------------------- softmax streams (placement: attn_w64_sched.inc)
+  // pair q of stream X: registers e, e+1 of S_X[h]; packed into word wd of P_X[ks]
+  template <int MODE, int X, int Q, int EL> MMPL_DEV void sm_e() {
+    constexpr int h = Q >> 3, e = (Q & 7) * 2 + EL;
+    if constexpr (MODE == 0)
+      asm volatile("v_exp_f32 %0, %1" : "=v"(t[X][Q & 1][EL]) : "v"(S[X][h][e]));
+    else
+      asm volatile("v_sub_f32 %0, %1, %2\n\tv_exp_f32 %0, %0" : "=&v"(t[X][Q & 1][EL]) : "v"(S[X][h][e]), "v"(mref[X]));
+  }
+  template <int MODE, int X, int Q> MMPL_DEV void sm_e0() { sm_e<MODE, X, Q, 0>(); }
+  template <int MODE, int X, int Q> MMPL_DEV void sm_e1() { sm_e<MODE, X, Q, 1>(); }
+  template <int MODE, int X, int Q> MMPL_DEV void sm_a0() {
+    if constexpr (Q == 0) la[X] = t[X][0][0];
+    else asm volatile("v_add_f32 %0, %0, %1" : "+v"(la[X]) : "v"(t[X][Q & 1][0]));
+  }
+  template <int MODE, int X, int Q> MMPL_DEV void sm_a1() {
+    if constexpr (Q == 0) lb[X] = t[X][0][1];
+    else asm volatile("v_add_f32 %0, %0, %1" : "+v"(lb[X]) : "v"(t[X][Q & 1][1]));
+  }
+  template <int MODE, int X, int Q> MMPL_DEV void sm_c() {
+    constexpr int ks = Q >> 2, wd = Q & 3;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(P[X][ks][wd]) : "v"(t[X][Q & 1][0]), "v"(t[X][Q & 1][1]));
+  }
+  // the tile stream X is about to start: mask the rows past the end of a page's ragged last tile
+  template <int X> MMPL_DEV void mask() {
+    const int valid = page_rows - crow[X];
+    if (valid < KVB) {
+      // register r of half h holds kv row 32 h + 8 (r >> 2) + (r & 3) + 4 hi: one compare of 4 hi against a scalar per register
+      // (written as asm so that the 32 compares do not all stay live in SGPR pairs at once)
+      const int hi4 = 4 * hi;
+      const float ninf = -INFINITY;
+      Ctx* self = this;
+      sfor<32>([self, hi4, ninf, valid](auto ii) {
+        constexpr int i = decltype(ii)::value, h = i >> 4, r = i & 15;
+        const int thr = valid - (32 * h + 8 * (r >> 2) + (r & 3));          // masked iff 4 hi >= thr
+        asm volatile("v_cmp_le_i32 vcc, %2, %1\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(self->S[X][h][r]) : "v"(hi4), "s"(thr), "v"(ninf) : "vcc");
+      });
+    }
+    crow[X] += KVB;
+    if (crow[X] >= page_rows) crow[X] = 0;
+  }
+  // Slow path of one tile of stream X (see the header): returns the tile's partial row sum.
+  template <int X> MMPL_DEV float slow(float lt) {
+    float mx = S[X][0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[X][0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[X][1][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (first[X]) {
+      first[X] = 0;
+      // first tile: stay on reference 0 if every row's maximum is moderate (the optimistic tile is then valid as computed)
+      if (!gen && !__any(!(fabsf(mx) <= FIRST_RANGE))) return lt;
+      mref[X] = mx;                                   // O = l = 0: nothing to rescale
+    } else {
+      const float m_new = fmaxf(mref[X], mx);
+      const float alpha = __builtin_amdgcn_exp2f(mref[X] - m_new);
+      mref[X] = m_new;
+      l[X] *= alpha;
+      sfor<64>([alpha](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        float v;
+        asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "i"(AO + 64 * X + i));
+        v *= alpha;
+        asm volatile("v_accvgpr_write_b32 a[%c0], %1" ::"i"(AO + 64 * X + i), "v"(v));
+      });
+    }
+    gen = 1;
+    lt = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int h = q >> 3, e = (q & 7) * 2;
+      const float a0 = __builtin_amdgcn_exp2f(S[X][h][e] - mref[X]);
+      const float a1 = __builtin_amdgcn_exp2f(S[X][h][e + 1] - mref[X]);
+      lt += a0 + a1;
+      P[X][q >> 2][q & 3] = pack2bf(a0, a1);
+    }
+    asm volatile("s_nop 1" ::: "memory");             // VALU-written P -> MFMA operand
+    return lt;
+  }
+  template <int MODE, int X> MMPL_DEV void finish() {
+    float lt = la[X] + lb[X];
+    if (first[X] || __any(!(lt <= (MODE == 0 ? BOUND_FAST : BOUND_GEN)))) lt = slow<X>(lt);
+    l[X] += lt;
+  }
 };
 
-// ---- single-instruction helpers (volatile: the hot loop is emitted in source order; the compiler only allocates registers)
-template <int X, int G> MMPL_DEV void mfma_qk(W64& w) {   // S_X[h] (+)= K frag G . Q_X[chunk]
-  constexpr int c = G >> 1, h = G & 1, qa = AQ + 32 * X + 4 * c;
-  if constexpr (c == 0)
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(w.S[X][h]) : "v"(w.kf[G]), "i"(qa), "i"(qa + 3));
-  else
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(w.S[X][h]) : "v"(w.kf[G]), "i"(qa), "i"(qa + 3));
-}
-template <int X, int G> MMPL_DEV void mfma_pv(W64& w) {   // O_X[nb] += V frag G . P_X[ks]
-  constexpr int ks = G >> 2, nb = G & 3, oa = AO + 64 * X + 16 * nb, va = AV + 4 * G;
-  asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], a[%c2:%c3], %4, a[%c0:%c1]" ::"i"(oa), "i"(oa + 15), "i"(va), "i"(va + 3),
-               "v"(w.P[X][ks]));
-}
-template <int G> MMPL_DEV void lds_k(W64& w, uint32_t addr) {   // fragment G = (chunk, half): addr already carries the chunk
-  asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(w.kf[G]) : "v"(addr), "i"((G & 1) * 32 * 256));
-}
-template <int G, int IMM> MMPL_DEV void lds_k_next(W64& w, uint32_t& addr) {   // move addr to the next chunk, then read
-  asm volatile("v_xor_b32 %1, %2, %1\n\tds_read_b128 %0, %1 offset:%c3" : "=v"(w.kf[G]), "+v"(addr) : "i"(IMM), "i"((G & 1) * 32 * 256));
-}
-template <int G> MMPL_DEV void lds_v(uint32_t addr) {           // fragment G = (ks, nb): addr already carries nb
-  constexpr int va = AV + 4 * G, off = (G >> 2) * 16 * 256;
-  asm volatile("ds_read_b64_tr_b16 a[%c1:%c2], %0 offset:%c3\n\tds_read_b64_tr_b16 a[%c4:%c5], %0 offset:%c6" ::"v"(addr), "i"(va),
-               "i"(va + 1), "i"(off), "i"(va + 2), "i"(va + 3), "i"(off + 8 * 256));
-}
-template <int IMM> MMPL_DEV uint32_t v_xor(uint32_t a) { uint32_t r; asm volatile("v_xor_b32 %0, %1, %2" : "=v"(r) : "i"(IMM), "v"(a)); return r; }
-// One asm statement per group of dependent VALU ops: hipcc pads a wait state wherever one statement's output feeds the next
-// statement, and knows nothing about the instructions inside (the trans -> VALU use distance is kept by the gap structure).
-MMPL_DEV void v_scale_exp2(float& p0, float& p1, float s0, float s1, float c, float nmc) {     // p = exp2(s*c + nmc)
-  asm volatile("v_fma_f32 %0, %2, %4, %5\n\tv_fma_f32 %1, %3, %4, %5\n\tv_exp_f32 %0, %0\n\tv_exp_f32 %1, %1"
-               : "=&v"(p0), "=&v"(p1) : "v"(s0), "v"(s1), "v"(c), "v"(nmc));
-}
-MMPL_DEV uint32_t v_sum_pack(float& la, float& lb, float p0, float p1) {                        // la += p0, lb += p1, pack(p0, p1)
-  uint32_t r;
-  asm volatile("v_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %4\n\tv_cvt_pk_bf16_f32 %2, %3, %4" : "+v"(la), "+v"(lb), "=v"(r) : "v"(p0), "v"(p1));
-  return r;
-}
-MMPL_DEV uint32_t v_pack(float p0, float p1) { uint32_t r; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(p0), "v"(p1)); return r; }
+#include "attn_w64_sched.inc"
 
-// LDS-DMA of one 1 KiB piece (4 rows x 256 B): M0 = LDS destination (written in the same statement that uses it; nothing the
-// compiler emits in this kernel reads M0), 1 wait state between the M0 write and the DMA
-template <int OFF> MMPL_DEV void dma16(const void* base, uint32_t voff, uint32_t lds_dst) {
-  asm volatile("s_add_u32 m0, %2, %c3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_dst), "i"(OFF)
-               : "memory", "scc");
-}
-
-// ---- one gap's share of the softmax of query block X (tile already masked): pair q = G >> 1 of the 16 register pairs
-template <int X, int G> MMPL_DEV void sm_gap(W64& w, float c) {
-  constexpr int q = G >> 1, h = q >> 3, e = (q & 7) * 2, ks = 2 * h + (e >> 3), wd = (e & 7) >> 1;
-  if constexpr ((G & 1) == 0) {
-    v_scale_exp2(w.p0, w.p1, w.S[X][h][e], w.S[X][h][e + 1], c, w.nmc[X]);
-  } else if constexpr (q == 0) {
-    w.la = w.p0;
-    w.lb = w.p1;
-    w.P[X][ks][wd] = v_pack(w.p0, w.p1);
-  } else {
-    w.P[X][ks][wd] = v_sum_pack(w.la, w.lb, w.p0, w.p1);
-  }
-}
-
-template <int X> MMPL_DEV void mask_tail(W64& w, int valid, int hi) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int kv = 8 * (r >> 2) + 4 * hi + (r & 3);
-    if (kv >= valid) w.S[X][0][r] = -INFINITY;
-    if (kv + 32 >= valid) w.S[X][1][r] = -INFINITY;
-  }
-}
-
-// Slow path of one tile of query block X: exact row max, move the reference, rescale O_X and l, recompute P and the tile sum.
-template <int X> MMPL_DEV float sm_slow(W64& w, float c) {
-  float mx = w.S[X][0][0];
-#pragma unroll
-  for (int r = 1; r < 16; ++r) mx = fmaxf(mx, w.S[X][0][r]);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) mx = fmaxf(mx, w.S[X][1][r]);
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  const float m_new = fmaxf(w.mref[X], mx);
-  const float alpha = __builtin_amdgcn_exp2f((w.mref[X] - m_new) * c);      // first tile: exp2(-inf) = 0 (O = l = 0)
-  w.mref[X] = m_new;
-  w.nmc[X] = -m_new * c;
-  w.l[X] *= alpha;
-  sfor<64>([&w, alpha](auto ii) {
-    constexpr int i = decltype(ii)::value;
-    float t;
-    asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(t) : "i"(AO + 64 * X + i));
-    t *= alpha;
-    asm volatile("v_accvgpr_write_b32 a[%c0], %1" ::"i"(AO + 64 * X + i), "v"(t));
-  });
-  float lt = 0.f;
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float a0 = __builtin_amdgcn_exp2f(fmaf(w.S[X][h][8 * cc + 2 * q], c, w.nmc[X]));
-        const float a1 = __builtin_amdgcn_exp2f(fmaf(w.S[X][h][8 * cc + 2 * q + 1], c, w.nmc[X]));
-        lt += a0 + a1;
-        w.P[X][2 * h + cc][q] = pack2bf(a0, a1);
-      }
-  return lt;
-}
-
-// end of a tile of query block X: accept the optimistic sum or redo the tile on the slow path
-template <int X> MMPL_DEV void sm_finish(W64& w, float c) {
-  float lt = w.la + w.lb;
-  if (__any(!(lt <= L_BOUND))) lt = sm_slow<X>(w, c);
-  w.l[X] += lt;
-}
-
-// RING: tiles per LDS ring = how far ahead the LDS-DMA runs (K(j+RING), V(j+RING-1) are issued during tile j).
-// ABL (dev builds only): timing ablations, results are garbage -- 1 no LDS-DMA in the loop, 2 no softmax, 4 no fragment reads.
-template <int RING, int ABL, bool SPLIT>
+template <bool SPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_w64_kernel(AttnArgs a, int local_base, int sp) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
@@ -198,7 +304,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   asm volatile("s_nop 0" ::: ALL_AGPRS);
   sfor<128>([](auto ii) { asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(AO + decltype(ii)::value)); });
 
-  // ---- Q fragments -> a[128:191]: lane (l31, hi) holds Q[row][16c + 8*hi .. +8] of its row in block A and in block B
+  // ---- Q fragments -> a[128:191], prescaled: lane (l31, hi) holds Q[row][16c + 8*hi .. +8] * scale * log2(e) (rounded to bf16)
+  const float c = a.scale * 1.4426950408889634f;
   {
     const bf16_t* qbase = a.q + head * 128 + 8 * hi;
 #pragma unroll
@@ -207,7 +314,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const bf16_t* qp = qbase + (size_t)qrow * a.ldq;
       u32x4 qf[8];
 #pragma unroll
-      for (int cc = 0; cc < 8; ++cc) qf[cc] = *reinterpret_cast<const u32x4*>(qp + 16 * cc);
+      for (int cc = 0; cc < 8; ++cc) {
+        qf[cc] = *reinterpret_cast<const u32x4*>(qp + 16 * cc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          qf[cc][j] = pack2bf(__uint_as_float(qf[cc][j] << 16) * c, __uint_as_float(qf[cc][j] & 0xffff0000u) * c);
+      }
       if (X == 0)
         sfor<32>([&qf](auto ii) { constexpr int i = decltype(ii)::value; asm volatile("v_accvgpr_write_b32 a[%c0], %1" ::"i"(AQ + i), "v"(qf[i >> 2][i & 3])); });
       else
@@ -220,173 +332,85 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int t_first = SPLIT ? (int)((long long)part * T_all / sp) : 0;
   const int T = SPLIT ? (int)((long long)(part + 1) * T_all / sp) - t_first : T_all;     // tiles of THIS block
 
-  // ---- LDS-DMA roles: wave w moves pieces w, w+4, w+8, w+12 (4 rows x 256 B each) of every K tile and of every V tile.  The
-  // LDS image is lane-linear, so the bank swizzle goes on the per-lane SOURCE chunk (K: chunk ^= row & 15; V: chunk ^=
-  // (row & 3) << 2; row & 15 = 4*wave + drow for all four pieces) and again on the fragment reads.
-  const int drow = lane >> 4, dchunk = lane & 15;
-  const int prow = 4 * wave + drow;                     // row of piece 0; piece k: + 16 k
-  uint32_t dko[4], dvo[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    dko[k] = (uint32_t)((prow + 16 * k) * a.ldk + ((dchunk ^ prow) << 3)) * 2u;
-    dvo[k] = (uint32_t)((prow + 16 * k) * a.ldv + ((dchunk ^ (drow << 2)) << 3)) * 2u;
+  Ctx k;
+  k.hi = hi;
+  k.k_pages = a.k_pages; k.v_pages = a.v_pages;
+  k.ldk = a.ldk; k.ldv = a.ldv; k.page_rows = a.page_rows; k.head = head; k.T = T;
+  k.drow = lane >> 4; k.dchunk = lane & 15;
+  k.prow = 16 * wave + k.drow;                        // LDS row of piece 4w; piece 4w + k: + 4 k
+  k.kpg = k.vpg = t_first / tiles_pp;
+  k.krow0 = k.vrow0 = (t_first % tiles_pp) * KVB;
+  k.kt = k.vt = 0;
+  k.kptr = a.k_pages[k.kpg] + (size_t)k.krow0 * a.ldk + head * 128 - DMA_BIAS / 2;
+  k.vptr = a.v_pages[k.vpg] + (size_t)k.vrow0 * a.ldv + head * 128 - DMA_BIAS / 2;
+  k.kslot = wave * 4096; k.vslot = RING * TILE + wave * 4096;
+  k.set_k_offsets(min(KVB - 1, a.page_rows - 1 - k.krow0));
+  k.set_v_offsets(min(KVB - 1, a.page_rows - 1 - k.vrow0));
+  k.l[0] = k.l[1] = 0.f;
+  k.mref[0] = k.mref[1] = 0.f;
+  k.first[0] = k.first[1] = 1;
+  k.gen = 0;
+  k.crow[0] = k.crow[1] = k.krow0;
+  // per-lane fragment read offsets (swizzled): koff(cs) = kbase ^ 32 cs, voff(nb) = vbase ^ 64 nb
+  k.kbase = l31 * 256 + 32 * ((l31 & 15) >> 1) + 16 * (hi ^ (l31 & 1));
+  {
+    const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+    k.vbase = RING * TILE + (4 * hi + (i16 >> 2)) * 256 + 64 * (i16 >> 2) + 32 * g16 + 8 * (i16 & 3);
   }
-  // issue cursors (next K tile / next V tile to fetch); they stop on the block's last tile, which is then simply re-fetched,
-  // so every event issues exactly 8 pieces and the counted waits below never change
-  struct Cur { const bf16_t* ptr; int row0, pg, t; };
-  Cur ck, cv;
-  ck.pg = cv.pg = t_first / tiles_pp;
-  ck.row0 = cv.row0 = (t_first % tiles_pp) * KVB;
-  ck.t = cv.t = 0;
-  ck.ptr = a.k_pages[ck.pg] + (size_t)ck.row0 * a.ldk + head * 128;
-  cv.ptr = a.v_pages[cv.pg] + (size_t)cv.row0 * a.ldv + head * 128;
-  uint32_t kslot = wave * 1024, vslot = RING * TILE + wave * 1024;          // LDS byte address of this wave's piece 0 in the ring slot
-  auto issue_k = [&](auto kk) {                         // piece k of the K tile under the cursor
-    constexpr int k = decltype(kk)::value;
-    uint32_t off = dko[k];
-    if (ck.row0 + KVB > a.page_rows)                    // ragged last tile of a page: clamp rows (masked in the softmax)
-      off = (uint32_t)(min(prow + 16 * k, a.page_rows - 1 - ck.row0) * a.ldk + ((dchunk ^ prow) << 3)) * 2u;
-    dma16<4096 * k>(ck.ptr, off, kslot);
-  };
-  auto issue_v = [&](auto kk) {
-    constexpr int k = decltype(kk)::value;
-    uint32_t off = dvo[k];
-    if (cv.row0 + KVB > a.page_rows)
-      off = (uint32_t)(min(prow + 16 * k, a.page_rows - 1 - cv.row0) * a.ldv + ((dchunk ^ (drow << 2)) << 3)) * 2u;
-    dma16<4096 * k>(cv.ptr, off, vslot);
-  };
-  auto advance = [&](Cur& cu, const bf16_t* const* pages, int ld, uint32_t& slot, uint32_t ring0) {
-    slot += TILE;
-    if (slot >= ring0 + RING * TILE) slot -= RING * TILE;
-    if (cu.t + 1 < T) {
-      ++cu.t;
-      cu.row0 += KVB;
-      cu.ptr += (size_t)KVB * ld;
-      if (cu.row0 >= a.page_rows) {
-        cu.row0 = 0;
-        ++cu.pg;
-        cu.ptr = pages[cu.pg] + head * 128;
-      }
-    }
-    asm volatile("" : "+s"(cu.ptr));
-  };
+  k.rk = TILE; k.rv = 0;
 
-  W64 w;
-  w.l[0] = w.l[1] = 0.f;
-  w.mref[0] = w.mref[1] = -INFINITY;
-  w.nmc[0] = w.nmc[1] = INFINITY;
-  const float c = a.scale * 1.4426950408889634f;
-
-  // ---- per-lane fragment read offsets (swizzled); chunk / d-block enter by XOR: koff(cs) = koff(0) ^ 32 cs, voff(nb) = voff(0) ^ 64 nb
-  const uint32_t kbase = l31 * 256 + 32 * ((l31 & 15) >> 1) + 16 * (hi ^ (l31 & 1));
-  const int i16 = lane & 15, g16 = (lane >> 4) & 1;
-  const uint32_t vbase = RING * TILE + (4 * hi + (i16 >> 2)) * 256 + 64 * (i16 >> 2) + 32 * g16 + 8 * (i16 & 3);
-
-  // ---- prologue: events -RING .. -1 of the DMA stream (event e = { K(e+RING), V(e+RING-1) }), then the K(0) fragments
-  sfor<4>(issue_k);
-  advance(ck, a.k_pages, a.ldk, kslot, 0);
+  // ---- prologue: DMA events -4 .. -1 (event e = { K(e+4), V(e+2) }), then the K(0) fragments
+  sfor<4>([&k](auto kk) { k.template dma_k<decltype(kk)::value>(); });
+  k.advance_k();
+  sfor<4>([&k](auto kk) { k.template dma_k<decltype(kk)::value>(); });
+  k.advance_k();
 #pragma unroll 1
-  for (int e = 1; e < RING; ++e) {
-    sfor<4>(issue_k);
-    sfor<4>(issue_v);
-    advance(ck, a.k_pages, a.ldk, kslot, 0);
-    advance(cv, a.v_pages, a.ldv, vslot, RING * TILE);
+  for (int e = 0; e < 2; ++e) {
+    sfor<4>([&k](auto kk) { k.template dma_k<decltype(kk)::value>(); });
+    sfor<4>([&k](auto kk) { k.template dma_v<decltype(kk)::value>(); });
+    k.advance_k();
+    k.advance_v();
   }
-  asm volatile("s_waitcnt vmcnt(%c0)\n\ts_barrier" ::"i"(8 * (RING - 1)) : "memory");
-  sfor<16>([&w, kbase](auto gi) { constexpr int g = decltype(gi)::value; lds_k<g>(w, kbase ^ (32 * (g >> 1))); });
+  asm volatile("s_waitcnt vmcnt(20)\n\ts_barrier" ::: "memory");
+  k.kaddr = k.kbase;
+  sfor<16>([&k](auto gi) { k.template lds_k<decltype(gi)::value>(); });
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-  uint32_t rk = TILE, rv = 0;                       // ring offsets of the tiles the NEXT B phase reads: K(j+1), V(j)
-  int crow[2];
-  crow[0] = crow[1] = (t_first % tiles_pp) * KVB;   // first kv row (within its page) of the tile each block's softmax is at
-  uint32_t vaddr[4];
-
-  // ---- phase A(j): MFMAs of query block A, softmax of query block B
-  auto phase_a = [&](auto has_qk, auto has_pv) {
-    constexpr bool QK = decltype(has_qk)::value, PV = decltype(has_pv)::value;
-    if constexpr (PV) {
-      const int valid = a.page_rows - crow[1];
-      if (valid < KVB) mask_tail<1>(w, valid, hi);
-      crow[1] += KVB;
-      if (crow[1] >= a.page_rows) crow[1] = 0;
-    }
-    sfor<32>([&](auto gi) {
-      constexpr int g = decltype(gi)::value;
-      if constexpr (g < 16) { if constexpr (QK) mfma_qk<0, g>(w); }
-      else { if constexpr (PV) mfma_pv<0, g - 16>(w); }
-      if constexpr (PV && !(ABL & 2)) sm_gap<1, g>(w, c);
-      if constexpr (PV && !(ABL & 4) && g == 0) lds_v<15>(vaddr[3]);
-      if constexpr (g == 3) {
-        if constexpr (QK) asm volatile("s_waitcnt vmcnt(%c0) lgkmcnt(0)\n\ts_barrier" ::"i"(8 * (RING - 2)) : "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-      if constexpr (QK && !(ABL & 1) && g >= 5 && g <= 11 && (g & 1)) issue_k(ic<(g - 5) / 2>{});
-      if constexpr (QK && !(ABL & 1) && g >= 13 && g <= 19 && (g & 1)) issue_v(ic<(g - 13) / 2>{});
-      if constexpr (QK && g == 21) {
-        advance(ck, a.k_pages, a.ldk, kslot, 0);
-        advance(cv, a.v_pages, a.ldv, vslot, RING * TILE);
-      }
-    });
-    if constexpr (PV && !(ABL & 2)) sm_finish<1>(w, c);
-  };
-  // ---- phase B(j): MFMAs of query block B, softmax of query block A, fragment reads of K(j+1) and V(j)
-  auto phase_b = [&](auto has_qk, auto has_pv) {
-    constexpr bool QK = decltype(has_qk)::value, PV = decltype(has_pv)::value;
-    uint32_t kaddr = 0;
-    if constexpr (QK) {
-      const int valid = a.page_rows - crow[0];
-      if (valid < KVB) mask_tail<0>(w, valid, hi);
-      crow[0] += KVB;
-      if (crow[0] >= a.page_rows) crow[0] = 0;
-      kaddr = kbase + rk;
-      vaddr[0] = vbase + rv;
-    }
-    sfor<32>([&](auto gi) {
-      constexpr int g = decltype(gi)::value;
-      if constexpr (g < 16) { if constexpr (QK) mfma_qk<1, g>(w); }
-      else { if constexpr (PV) mfma_pv<1, g - 16>(w); }
-      if constexpr (QK) {
-        if constexpr (!(ABL & 2)) sm_gap<0, g>(w, c);
-        if constexpr (!(ABL & 4) && g >= 1 && g <= 16) {
-          constexpr int f = g - 1;                       // K(j) fragment f was last read by MFMA f of this phase
-          if constexpr ((f & 1) == 0 && f > 0) lds_k_next<f, (32 * (f >> 1)) ^ (32 * ((f >> 1) - 1))>(w, kaddr);
-          else lds_k<f>(w, kaddr);
-        }
-        if constexpr (g >= 13 && g <= 15) vaddr[g - 12] = v_xor<64 * (g - 12)>(vaddr[0]);
-        if constexpr (g == 22) asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");     // the 16 K reads are older than the 10 V reads since
-        if constexpr (!(ABL & 4) && g >= 17) lds_v<g - 17>(vaddr[(g - 17) & 3]);
-      }
-    });
-    if constexpr (QK) {
-      if constexpr (!(ABL & 2)) sm_finish<0>(w, c);
-      rk += TILE; if (rk >= RING * TILE) rk = 0;
-      rv += TILE; if (rv >= RING * TILE) rv = 0;
-    }
-  };
-  using std::true_type;
-  using std::false_type;
-
-  phase_a(true_type{}, false_type{});
-  phase_b(true_type{}, false_type{});
+  w64_phase_a<0, true, false, true, false>(k);
+  w64_phase_b<0, true, false, true, false>(k);
+  // two plain loops rather than one loop with a mode branch inside (which hipcc cannot allocate without spilling into the
+  // accumulator file): the wave leaves FAST mode at most once
+  int j = 1;
 #pragma unroll 1
-  for (int j = 1; j < T; ++j) {
-    phase_a(true_type{}, true_type{});
-    phase_b(true_type{}, true_type{});
+  for (; j < T && !k.gen; ++j) {
+    w64_phase_a<0, true, true, true, true>(k);
+    w64_phase_b<0, true, true, true, true>(k);
   }
-  phase_a(false_type{}, true_type{});
-  phase_b(false_type{}, true_type{});
+#pragma unroll 1
+  for (; j < T; ++j) {
+    w64_phase_a<1, true, true, true, true>(k);
+    w64_phase_b<1, true, true, true, true>(k);
+  }
+  if (!k.gen) {
+    w64_phase_a<0, false, true, false, true>(k);
+    w64_phase_b<0, false, true, false, true>(k);
+  } else {
+    w64_phase_a<1, false, true, false, true>(k);
+    w64_phase_b<1, false, true, false, true>(k);
+  }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
   // ---- epilogue: lane (q = l31, hi) holds O_X[q][32*nb + 8*g + 4*hi + {0..3}] in a[64 X + 16 nb + 4 g ..+3]
 #pragma unroll
   for (int X = 0; X < 2; ++X) {
-    const float l_tot = w.l[X] + __shfl_xor(w.l[X], 32, 64);
+    const float l_tot = k.l[X] + __shfl_xor(k.l[X], 32, 64);
     float o[64];
     if (X == 0) sfor<64>([&o](auto ii) { constexpr int i = decltype(ii)::value; asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(o[i]) : "i"(AO + i)); });
     else sfor<64>([&o](auto ii) { constexpr int i = decltype(ii)::value; asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(o[i]) : "i"(AO + 64 + i)); });
     const int rr = wave * 64 + 32 * X + l31;
     if (SPLIT) {
-      // partial of this KV range: O (fp32, relative to m_ref), then m, l per row -- [tail block][part][256 rows][128 + 2]
+      // partial of this KV range: O (fp32, relative to m_ref), then m (raw score units, as attn_merge_kernel expects), l per
+      // row -- [tail block][part][256 rows][128 + 2]
       float* pbase = a.split_ws + ((size_t)tail_idx * sp + part) * (QB * 130);
       float* op = pbase + (size_t)rr * 128 + 4 * hi;
 #pragma unroll
@@ -395,7 +419,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int g = 0; g < 4; ++g)
           *reinterpret_cast<f32x4*>(op + 32 * nb + 8 * g) = f32x4{o[16 * nb + 4 * g], o[16 * nb + 4 * g + 1], o[16 * nb + 4 * g + 2], o[16 * nb + 4 * g + 3]};
       if (hi == 0) {
-        pbase[QB * 128 + rr] = w.mref[X];
+        pbase[QB * 128 + rr] = k.mref[X] / c;
         pbase[QB * 129 + rr] = l_tot;
       }
     } else {
@@ -419,35 +443,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 }  // namespace
 
-namespace {
-template <int RING, int ABL>
-const void* w64_sym(int split) {
-  return split ? reinterpret_cast<const void*>(attn_w64_kernel<RING, ABL, true>) : reinterpret_cast<const void*>(attn_w64_kernel<RING, ABL, false>);
+int mmpl_attention_w64_smem() { return W64_SMEM; }
+const void* mmpl_attention_w64_symbol(int split) {
+  return split ? reinterpret_cast<const void*>(attn_w64_kernel<true>) : reinterpret_cast<const void*>(attn_w64_kernel<false>);
 }
-template <int RING, int ABL>
-void w64_launch(const AttnArgs& a, int blocks, int local_base, int sp, bool split, hipStream_t s) {
-  if (split) hipLaunchKernelGGL((attn_w64_kernel<RING, ABL, true>), dim3(blocks), dim3(256), 2 * RING * TILE, s, a, local_base, sp);
-  else hipLaunchKernelGGL((attn_w64_kernel<RING, ABL, false>), dim3(blocks), dim3(256), 2 * RING * TILE, s, a, local_base, sp);
-}
-// dev knobs, read once per process: MMPL_W64_RING (2..4), MMPL_W64_ABL (timing ablations, garbage results)
-int w64_ring() { static const int r = getenv("MMPL_W64_RING") ? atoi(getenv("MMPL_W64_RING")) : 4; return r; }
-int w64_abl() { static const int r = getenv("MMPL_W64_ABL") ? atoi(getenv("MMPL_W64_ABL")) : 0; return r; }
-#define W64_DISPATCH(expr)                                                   \
-  do {                                                                       \
-    const int r_ = w64_ring(), b_ = w64_abl();                               \
-    if (b_ == 1) { constexpr int RING = 2, ABL = 1; expr; }                  \
-    else if (b_ == 2) { constexpr int RING = 2, ABL = 2; expr; }             \
-    else if (b_ == 4) { constexpr int RING = 2, ABL = 4; expr; }             \
-    else if (b_ == 6) { constexpr int RING = 2, ABL = 6; expr; }             \
-    else if (b_ == 7) { constexpr int RING = 2, ABL = 7; expr; }             \
-    else if (r_ == 2) { constexpr int RING = 2, ABL = 0; expr; }             \
-    else if (r_ == 3) { constexpr int RING = 3, ABL = 0; expr; }             \
-    else { constexpr int RING = 4, ABL = 0; expr; }                          \
-  } while (0)
-}  // namespace
-
-int mmpl_attention_w64_smem() { int v = 0; W64_DISPATCH(v = 2 * RING * TILE; (void)ABL); return v; }
-const void* mmpl_attention_w64_symbol(int split) { const void* p = nullptr; W64_DISPATCH(p = (w64_sym<RING, ABL>(split))); return p; }
 void mmpl_launch_attention_w64(const AttnArgs& a, int blocks, int local_base, int sp, bool split, hipStream_t s) {
-  W64_DISPATCH((w64_launch<RING, ABL>(a, blocks, local_base, sp, split, s)));
+  if (split) hipLaunchKernelGGL(attn_w64_kernel<true>, dim3(blocks), dim3(256), W64_SMEM, s, a, local_base, sp);
+  else hipLaunchKernelGGL(attn_w64_kernel<false>, dim3(blocks), dim3(256), W64_SMEM, s, a, local_base, sp);
 }

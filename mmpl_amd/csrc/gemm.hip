@@ -329,93 +329,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 constexpr int BM3 = 256, BN3 = 256;
 
 // ---------------------------------------------------------------------------------------------------------------
-// v4 (MMPL_GEMM_V4=1; the lock-step predecessor of v6): v3 geometry with BK = 64 and a 2-stage ring (2 x 64 KiB): half as many barriers per MFMA, the DMA of
-// tile t+1 has one whole iteration (64 MFMAs per wave) to land; plain vmcnt(0) + raw barrier per tile.
+// (v4 -- the lock-step predecessor of v6: same tile and 2-stage ring, both wave groups reading then multiplying together,
+// 1070-1200 TFLOP/s -- was removed in round 2: unreachable in normal operation; its geometry constants stay)
 constexpr int BK4 = 64, A4_BYTES = BM3 * BK4 * 2, STAGE4 = 2 * A4_BYTES;
 MMPL_DEV int swz64(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
-
-template <int EPI>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_v4_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tiles_m = (g.M + BM3 - 1) / BM3, tiles_n = (g.N + BN3 - 1) / BN3;
-  const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int GROUP = g.group;
-  const int per_group = GROUP * tiles_n;
-  const int gid = bid / per_group;
-  const int first_m = gid * GROUP;
-  const int gsz = min(tiles_m - first_m, GROUP);
-  const int tm = first_m + (bid % per_group) % gsz;
-  const int tn = (bid % per_group) / gsz;
-  const int m0 = tm * BM3, n0 = tn * BN3;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-
-  const bf16_t* a_src[4];
-  const bf16_t* w_src[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int p = (j * 8 + wave) * 64 + lane, row = p >> 3, c = (p & 7) ^ (row & 7);
-    a_src[j] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + c * 8;
-    w_src[j] = g.W + (size_t)min(n0 + row, g.N - 1) * g.ldw + c * 8;
-  }
-  auto issue = [&](int t) {
-    char* st = smem + (t & 1) * STAGE4;
-    const int koff = t * BK4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(a_src[j] + koff, st + (j * 8 + wave) * 1024);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(w_src[j] + koff, st + A4_BYTES + (j * 8 + wave) * 1024);
-  };
-  f32x4 acc[2][4][4];
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int frow = lane & 15, fchunk = lane >> 4;
-  int a_off[8], w_off[4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) a_off[i] = swz64(128 * wm + 16 * i + frow, fchunk);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) w_off[i] = A4_BYTES + swz64(64 * wn + 16 * i + frow, fchunk);
-  const int nt = g.K / BK4;
-  issue(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) issue(t + 1);
-    const char* st = smem + (t & 1) * STAGE4;
-    // both k-steps' fragments are requested up front: the second step's LDS reads land under the first step's MFMAs
-    bf16x8 af[2][8], wf[2][4];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wf[ks][i] = *reinterpret_cast<const bf16x8*>(st + (w_off[i] ^ (ks << 6)));
-#pragma unroll
-      for (int i = 0; i < 8; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(st + (a_off[i] ^ (ks << 6)));
-    }
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i >> 2][i & 3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[i >> 2][i & 3][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-  gemm_epilogue<EPI>(g, acc[0], m0 + 128 * wm, n0 + 64 * wn, frow, fchunk);
-  gemm_epilogue<EPI>(g, acc[1], m0 + 128 * wm + 64, n0 + 64 * wn, frow, fchunk);
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // v6 "ping-pong" (default for large problems): v4's tile (256x256x64, 8 waves 2x4, 2-stage LDS-DMA ring) with the two wave groups (waves 0-3 / 4-7:
@@ -423,9 +340,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 //   R_t = { request its 24 LDS fragments of tile t (+ group A: issue ALL 64 LDS-DMA ops of tile t+1) }
 //   M_t = { 64 MFMAs }
 // and while one group is in M the other is in R, so each SIMD's matrix pipe is fed by one wave while its partner's
-// LDS reads / DMA issue stalls happen in the shadow, instead of both waves reading, then both multiplying (v4).
+// LDS reads / DMA issue stalls happen in the shadow, instead of both waves reading, then both multiplying (the removed v4).
 // A DMA op is global_load_lds_dwordx4 voff, s[base] with voff = (clamped row * ld + swizzled chunk) * 2: needs
-// M * lda * 2 and N * ldw * 2 < 4 GiB (checked by the launcher, else v4).  Bit-identical to v4 (same MFMA order);
+// M * lda * 2 and N * ldw * 2 < 4 GiB (checked by the launcher, else the 64-bit-addressed v2).  Same MFMA order as v4 was;
 // measured in one process on the 14B/720p shapes: +4 ... +14 % over v4 (1220-1290 vs 1070-1200 TFLOP/s, 1415 vs 1310
 // at 8192^3).  With the DMA ops removed the same kernel runs at 1450-1470: the LDS-DMA issue stalls (~100 cycles per
 // op) are the remaining cost.  A BK = 32 / 4-deep-ring variant in which both groups issue their own DMA ops inside
@@ -552,17 +469,6 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
 }
 
 template <int EPI>
-hipError_t launch_v4(const GemmArgs& g, hipStream_t s) {
-  constexpr int smem = 2 * STAGE4;
-  if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v4_kernel<EPI>), smem); e != hipSuccess) return e;
-  const int tiles = ((g.M + BM3 - 1) / BM3) * ((g.N + BN3 - 1) / BN3);
-  GemmArgs g2 = g;
-  g2.group = 4;
-  hipLaunchKernelGGL(gemm_bf16_v4_kernel<EPI>, dim3(tiles), dim3(512), smem, s, g2);
-  return hipGetLastError();
-}
-
-template <int EPI>
 hipError_t launch_v2(const GemmArgs& g, hipStream_t s) {
   constexpr int smem = NSTAGE2 * STAGE2;
   if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v2_kernel<EPI>), smem); e != hipSuccess) return e;
@@ -574,11 +480,10 @@ hipError_t launch_v2(const GemmArgs& g, hipStream_t s) {
 template <int EPI>
 hipError_t launch(const GemmArgs& g, hipStream_t s) {
   // kernel-selection overrides for A/B runs, read once per process
-  static const bool env_v1 = getenv("MMPL_GEMM_V1") != nullptr, env_v2 = getenv("MMPL_GEMM_V2") != nullptr,
-                    env_v4 = getenv("MMPL_GEMM_V4") != nullptr;
+  static const bool env_v1 = getenv("MMPL_GEMM_V1") != nullptr, env_v2 = getenv("MMPL_GEMM_V2") != nullptr;
   const bool big = g.batch <= 1 && g.M >= 1024 && g.N >= 256 && g.K >= 128 && !env_v1 && !env_v2;
-  if (big && !env_v4 && (long long)g.M * g.lda < (1ll << 31) && (long long)g.N * g.ldw < (1ll << 31)) return launch_v6<EPI>(g, s);
-  if (big) return launch_v4<EPI>(g, s);
+  // v6 addresses its operands with 32-bit byte offsets from the base pointers; anything larger goes to v2 (64-bit pointers)
+  if (big && (long long)g.M * g.lda < (1ll << 31) && (long long)g.N * g.ldw < (1ll << 31)) return launch_v6<EPI>(g, s);
   if (g.batch <= 1 && g.M >= 1024 && g.N >= 128 && g.K >= 128 && !env_v1) return launch_v2<EPI>(g, s);
   constexpr int smem = 4 * TILE_BYTES;
   if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_kernel<EPI>), smem); e != hipSuccess) return e;

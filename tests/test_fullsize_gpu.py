@@ -28,7 +28,7 @@ def _grouped_sdpa(q, k, v, group=4):
     return torch.cat(outs, dim=2).contiguous()
 
 
-def _stages(cfg_name, lat, layers=None, seed=21):
+def _stages(cfg_name, lat, layers=None, seed=21, mode="t2v"):
     from mmpl_amd.dit import DitEngine
     from mmpl_amd.synthetic import WAN_CONFIGS, dit_state_dict
     from oracle import stage_ref
@@ -52,15 +52,16 @@ def _stages(cfg_name, lat, layers=None, seed=21):
     ocross = [None] * cfg["num_layers"]
     vis = stage_ref.VisIndex()
     errs = []
-    for si, frames in enumerate(stage_ref.stage_frames(stage_ref.T2V_CLEAN_STEPS)):
-        if si == 2:
+    clean = stage_ref.T2V_CLEAN_STEPS if mode == "t2v" else stage_ref.I2V_CLEAN_STEPS
+    for si, frames in enumerate(stage_ref.stage_frames(clean)):
+        if mode == "t2v" and si == 2:      # I2V never hides frames 19, 20 (MMPL_i2v/pipeline/casual_fps_inference.py:253-335)
             vis.hide()
-        if si == 3:
+        if mode == "t2v" and si == 3:
             vis.show()
         vis.on_forward(frames)
         order = vis.slots()
         x = noise[frames].contiguous()
-        t = torch.full([len(frames)], (999.0, 750.0, 402.0, 92.0)[si], dtype=torch.float32, device=dev)
+        t = torch.full([len(frames)], (999.0, 750.0, 402.0, 92.0, 0.0)[si], dtype=torch.float32, device=dev)
         ws = stage_ref.write_slots_for(frames)
         y = eng.forward(x, t, frames, ws, order, kc, vc, ck, cv)
         yo = W.dit_forward(sd, ocfg, x.permute(1, 0, 2, 3), t.view(1, -1), ctx, okv, ocross, frames, ws, order,
@@ -102,6 +103,15 @@ def test_full_size_forward_all_stage_patterns(cfg_name, lat):
     errs = _stages(cfg_name, lat)
     print(f"{cfg_name} {lat}: rel_l2(HIP, oracle on device) per stage = " + ", ".join(f"{e:.3e}" for e in errs))
     assert max(errs) < TOL
+
+
+def test_full_size_forward_i2v_stage_patterns():
+    """The I2V stage plan at 14B/720p (BASELINE.json configs[4] shapes on one GPU): query / visible frames (1,1) image
+    latent, (1,2), (7,9) anchors, (6,15) with 19,20 still visible, (6,21) non-persisting
+    (MMPL_i2v/pipeline/casual_fps_inference.py:253-255)."""
+    errs = _stages("14B", (90, 160), mode="i2v")
+    print("14B (90, 160) i2v: rel_l2(HIP, oracle on device) per stage = " + ", ".join(f"{e:.3e}" for e in errs))
+    assert len(errs) == 5 and max(errs) < TOL
 
 
 def test_vae_720p_decode_encode_vs_device_evaluated_oracle():

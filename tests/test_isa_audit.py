@@ -1,0 +1,44 @@
+"""Build-time proofs the hand-written asm relies on (CDNA guide 5.7 items 1 and 4), checked on the ISA hipcc actually emits.
+
+* attn_w64.hip names the accumulator registers a[0:255] literally: valid only if the compiler never touches the accumulator file
+  itself (a spill or a copy into it would silently corrupt O / Q / V fragments), spills nothing and uses no scratch.
+* the LDS-DMA statements of attn_w64.hip, attention.hip and gemm.hip write M0 without declaring it (an "m0" clobber only draws a
+  warning and a save / restore pair per DMA op costs issue slots in the hot loops): valid only if no compiler-generated
+  instruction of those translation units reads or writes M0.
+* attn_w64_sched.inc is what tools/gen_attn_w64.py generates.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+CSRC = os.path.join(ROOT, "mmpl_amd", "csrc")
+
+hipcc = pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
+
+
+@hipcc
+def test_attn_w64_owns_the_accumulator_file(tmp_path):
+    import audit_w64
+    problems, info = audit_w64.audit(str(tmp_path))
+    assert not problems, problems
+    assert info["agpr_count"] == [256, 256] and all(v <= 512 for v in info["vgpr_count"])
+
+
+@hipcc
+@pytest.mark.parametrize("src", ["attention.hip", "gemm.hip"])
+def test_compiler_never_touches_m0(tmp_path, src):
+    import audit_w64
+    problems, _ = audit_w64.audit(str(tmp_path), os.path.join(CSRC, src), own_agprs=False)
+    assert not problems, problems
+
+
+def test_schedule_include_is_current(tmp_path):
+    import gen_attn_w64
+    committed = open(gen_attn_w64.OUT).read()
+    gen_attn_w64.OUT = str(tmp_path / "sched.inc")
+    gen_attn_w64.emit()
+    assert open(gen_attn_w64.OUT).read() == committed, "run python tools/gen_attn_w64.py"

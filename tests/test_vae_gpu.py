@@ -65,3 +65,19 @@ def test_decode_vs_oracle_other_geometry():
     e = rel_l2(out, ref)
     print(f"decode 6x10: rel_l2 = {e:.3e}")
     assert e < 3e-2
+
+
+def test_decode_real_handoff_artefact_vs_oracle():
+    """Realistic latent statistics: a spatial crop of the reference tree's real left-over hand-off tensor
+    (MMPL_i2v/latents_chunk4.pt: frame 0 + the last two anchors, mean -0.13 / std 0.96; tests/golden/make_golden_vae.py)
+    decoded by the HIP VAE and by the oracle."""
+    from oracle import vae_ref
+    art = torch.load(f"{GOLDEN}/handoff_artefact_crop.pt")          # bf16 [1, 3, 16, 16, 24]
+    assert art.shape == (1, 3, 16, 16, 24) and art.dtype == torch.bfloat16
+    eng, sd = _engine((16, 24))
+    out = eng.decode(art[0], MEAN, STD)                               # [9, 3, 128, 192]
+    torch.cuda.synchronize()
+    ref = vae_ref.decode_to_pixel(sd, art, MEAN, STD)[0]
+    e = rel_l2(out, ref)
+    print(f"decode of the real hand-off artefact crop: rel_l2(HIP, oracle) = {e:.3e}")
+    assert out.shape == (9, 3, 128, 192) and e < 3e-2
