@@ -14,8 +14,21 @@ step-equivalents (408 forwards), hence
                                                            (whole-job: summed over ranks, each rank = one chunk)
 
 Inputs (weights, KV caches, context, latents) are synthetic and resident in HBM before the timed region.
-Extra JSON objects: `roofline` for the dominant kernel (self-attention; MFMA bound) from hipEvent pairs recorded
-around every launch inside the timed region, `cpu_baseline` = the oracle (a CPU port) timed on a bounded sample.
+
+What is timed: by default every step is ONE hipGraph replay (both forwards + the fused CFG / UniPC update with its scalars
+in device tables: the north star's "hipGraph capture of one denoise step", exactly what
+mmpl_amd.pipeline.CausalFPSInferencePipeline replays 50 times per stage).  `--eager` times plain launches instead.  After
+the timed region one more rotation of the four stages runs eagerly with a hipEvent pair around every self-attention
+launch on the launch stream: that pass gives the `eager` figures printed beside the headline and the `roofline` object
+(per-kernel events cannot be recorded inside a graph replay; the kernels are the same binaries with the same arguments,
+and the rocprofv3 kernel trace of this command, profiles/, covers both passes).  `cpu_baseline` = the oracle (a CPU port)
+timed on a bounded sample: one transformer block per stage shape.
+
+N > 1: one process per GPU.  `value` is the rate ONE video can be generated at: lane l+1 cannot start its chunk before
+lane l has finished its anchor stage, so at most chunk_time / anchor_time (~3.5 at 14B/720p) chunk lanes are ever busy;
+from 4 ranks on the ranks are therefore paired (cond | uncond branch of the classifier-free guidance on two GPUs, the
+reference's device_cond / device_uncond seam) and W/2 lanes run twice as fast (`--no-cfg-split` / `--cfg-split` override).
+The N-independent-chunks aggregate is printed as `value_independent_chunks`.
 """
 from __future__ import annotations
 
@@ -53,40 +66,63 @@ def parse():
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-region) VAE decode measurement")
     ap.add_argument("--cfg-split", action="store_true",
                     help="N/2 chunk lanes x (cond, uncond) rank pairs exchanging flow predictions every step "
-                         "(the reference's device_cond/device_uncond seam) instead of N chunk lanes")
+                         "(the reference's device_cond/device_uncond seam) instead of N chunk lanes; default from 4 ranks on")
+    ap.add_argument("--no-cfg-split", action="store_true", help="N chunk lanes whatever N is")
+    ap.add_argument("--eager", action="store_true", help="time plain launches instead of one hipGraph replay per step")
+    ap.add_argument("--cpu-budget-s", type=float, default=150.0, help="stop adding stage shapes to the CPU baseline after this many seconds")
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, lat_h, lat_w, chunk_flops):
-    """Oracle (CPU port of the reference path) on a bounded sample: ONE transformer block of the benchmarked model
-    at the s0 stage shape (2 query frames attending 2 frames), all host threads.  Reported in the metric's unit by
-    scaling with algorithmic FLOPs (a chunk is ~481 PFLOP at 14B/720p -- hours on a CPU)."""
+def cpu_baseline(cfg, lat_h, lat_w, stage_shapes, budget_s):
+    """Oracle (CPU port of the reference path) on a bounded sample: ONE transformer block of the benchmarked model per
+    stage shape, all host threads; s0 is run 3 times after a warm-up, the larger shapes once each while the
+    time budget lasts (a shape not reached is priced at the FLOP rate of the measured ones).  Reported in the metric's unit:
+    chunk = 102 forwards per stage x num_layers blocks (a chunk is ~481 PFLOP at 14B/720p -- hours on a CPU)."""
     from mmpl_amd.synthetic import dit_state_dict
     from oracle import wan_dit_ref as W
     one = dict(cfg, num_layers=1)
     ocfg = W.DitCfg(**one)
     sd = dit_state_dict(one, seed=0)
     gh, gw = lat_h // 2, lat_w // 2
-    S, nF = gh * gw, 2
-    x = torch.randn(1, nF * S, ocfg.dim).to(torch.bfloat16)
-    e0 = (torch.randn(1, nF, 6, ocfg.dim) * 0.1).to(torch.bfloat16)
-    ctx = torch.randn(1, 512, ocfg.dim).to(torch.bfloat16)
-    kv = W.new_kv_cache(ocfg, 2, S)[0]
-    ck, cv = W.cross_kv(sd, ocfg, 0, ctx)
+    S = gh * gw
     freqs = W.rope_table(128)
-    reps = 3                                       # ~4 s each on the GPU box's host: a 10-15 s sample
-    with torch.no_grad():
-        W.block_forward(sd, ocfg, 0, x, e0, kv, ck, cv, [0, 1], [0, 1], [0, 1], S, gh, gw, freqs)   # untimed: thread pool / allocator warm-up
-        t0 = time.time()
-        for _ in range(reps):
-            W.block_forward(sd, ocfg, 0, x, e0, kv, ck, cv, [0, 1], [0, 1], [0, 1], S, gh, gw, freqs)
-    dt = (time.time() - t0) / reps
-    Lq = nF * S
-    flops = 2.0 * Lq * (6.0 * ocfg.dim ** 2 + 2.0 * ocfg.dim * ocfg.ffn_dim) + 4.0 * Lq * Lq * ocfg.dim + 4.0 * Lq * 512 * ocfg.dim
-    rate = flops / dt
-    return {"value": 21.0 / (chunk_flops / rate), "unit": "latent-frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle block_forward, 1 of {cfg['num_layers']} blocks, stage s0 (Lq=Lkv={Lq}), mean of {reps} runs of {dt:.1f} s, "
-                      f"{rate / 1e12:.3f} TFLOP/s; extrapolated by algorithmic FLOPs to one 408-forward chunk"}
+    ctx = torch.randn(1, 512, ocfg.dim).to(torch.bfloat16)
+    ck, cv = W.cross_kv(sd, ocfg, 0, ctx)
+    t_start, secs, flops, notes = time.time(), [], [], []
+    for si, (nq, nkv) in enumerate(stage_shapes):
+        Lq = nq * S
+        fl = 2.0 * Lq * (6.0 * ocfg.dim ** 2 + 2.0 * ocfg.dim * ocfg.ffn_dim) + 4.0 * Lq * (nkv * S) * ocfg.dim + 4.0 * Lq * 512 * ocfg.dim
+        flops.append(fl)
+        if si > 0 and time.time() - t_start + (fl / (sum(flops[:len(secs)]) / sum(secs))) > budget_s:
+            continue
+        persist = nkv <= nq or si < 3                  # the last T2V / I2V stage attends its own K/V without persisting them
+        n_slots = nkv if persist else nkv - nq
+        kv = W.new_kv_cache(ocfg, max(n_slots, nq), S)[0]
+        kv["k"].normal_()
+        kv["v"].normal_()
+        x = torch.randn(1, Lq, ocfg.dim).to(torch.bfloat16)
+        e0 = (torch.randn(1, nq, 6, ocfg.dim) * 0.1).to(torch.bfloat16)
+        frames = list(range(nq))
+        ws = frames if persist else [-1] * nq
+        vis = list(range(nkv)) if persist else list(range(nkv - nq))
+        reps = 3 if si == 0 else 1
+        with torch.no_grad():
+            if si == 0:
+                W.block_forward(sd, ocfg, 0, x, e0, kv, ck, cv, frames, ws, vis, S, gh, gw, freqs)   # untimed: thread pool / allocator warm-up
+            t0 = time.time()
+            for _ in range(reps):
+                W.block_forward(sd, ocfg, 0, x, e0, kv, ck, cv, frames, ws, vis, S, gh, gw, freqs)
+        dt = (time.time() - t0) / reps
+        secs.append(dt)
+        notes.append(f"s{si} (Lq={Lq}, Lkv={nkv * S}) {dt:.1f} s x{reps}")
+        del kv, x
+    rate = sum(flops[:len(secs)]) / sum(secs)
+    stage_block_s = secs + [f / rate for f in flops[len(secs):]]
+    chunk_s = 102.0 * cfg["num_layers"] * sum(stage_block_s)
+    return {"value": 21.0 / chunk_s, "unit": "latent-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle block_forward, 1 of {cfg['num_layers']} blocks per stage shape: " + ", ".join(notes) +
+                      (f"; {len(flops) - len(secs)} larger shape(s) priced at the measured {rate / 1e12:.2f} TFLOP/s (time budget)" if len(secs) < len(flops) else
+                       f"; {rate / 1e12:.2f} TFLOP/s") + "; a chunk = 102 forwards per stage x all blocks"}
 
 
 def main():
@@ -98,11 +134,15 @@ def main():
     if world > 1 or "RANK" in os.environ:      # (a 1-rank torchrun launch exercises the RCCL init / barrier / all-reduce path too)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        import datetime
+        # the wavefront's receives wait for whole anchor stages (minutes at 14B/720p): never the 10-minute default
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), timeout=datetime.timedelta(hours=4))
     assert args.steps > 0 and args.warmup >= 0
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     pair, lanes, lane, n_lanes = None, None, rank, world
+    if not args.cfg_split and not args.no_cfg_split and world >= 4 and world % 2 == 0:
+        args.cfg_split = True            # more chunk lanes than the wavefront can keep busy: spend the ranks on the CFG pair instead
     if args.cfg_split:
         assert world >= 2 and world % 2 == 0, "--cfg-split needs an even number of ranks"
         from mmpl_amd.handoff import CfgPair
@@ -154,9 +194,20 @@ def main():
     handoff_recv = torch.zeros_like(handoff_send)
     side = torch.cuda.Stream(device=dev)
 
-    def one_step(i):
+    def one_step(i, eager=False):
         st = stage_state[i % 4]
         sched = st["sched"]
+        if st.get("graph") is not None and not eager:
+            # ONE hipGraph per denoise step: both forwards + CFG / UniPC with device-resident scalars; the device step counter
+            # and the timestep tensor advance inside the graph, the host only rewinds them after the 50th replay
+            if st["replays"] >= 50:
+                sched.reset_step_table(st["t"])
+                st["replays"] = 0
+            st["graph"].replay()
+            st["replays"] += 1
+            if i % 4 == 1:
+                handoff_exchange(st)
+            return
         if sched.step_index >= 50:
             sched.set_timesteps(50, shift=5.0)
         st["t"].fill_(float(sched.timesteps[sched.step_index]))
@@ -198,6 +249,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    use_graph = pair is None and not args.eager           # (the CFG pair's per-step all-gather is a host-issued RCCL call)
+    if use_graph:
+        for st in stage_state:                              # eager warm-up of every launch shape, then capture
+            for which, out in ((0, st["fc"]), (1, st["fu"])):
+                kc, vc, ck, cv = caches[which]
+                st["t"].fill_(999.0)
+                eng.forward(st["lat"], st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out)
+            sched = st["sched"]
+            sched.build_step_table(5.0, dev)
+            sched._ensure_state(st["lat"])
+            st["t"].fill_(float(sched.timesteps[0]))
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for which, out in ((0, st["fc"]), (1, st["fu"])):
+                    kc, vc, ck, cv = caches[which]
+                    eng.forward(st["lat"], st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out)
+                sched.step_cfg_table(st["fc"], st["fu"], st["lat"], st["t"])
+            st["graph"], st["replays"] = g, 0
     for i in range(args.warmup):
         one_step(i)
     handoff_exchange(stage_state[1])       # untimed: the p2p communicators exist before the timed region whatever --warmup is
@@ -205,7 +275,7 @@ def main():
         pair.exchange(stage_state[0]["mine"], stage_state[0]["flow"])
     torch.cuda.current_stream().wait_stream(side)
     barrier()
-    if not args.no_profile:
+    if not args.no_profile and not use_graph:
         lib.mmpl_profile_enable(1 if args.profile_all else ((1 << 1) << 1))      # default: kind 1 = self-attention only
     # the K timed steps keep rotating through the four stage shapes; every step is also bracketed by a HIP event pair so
     # that the chunk time can be assembled per stage (exact for any K, not only multiples of 4)
@@ -219,6 +289,25 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     step_s = [e0.elapsed_time(e1) * 1e-3 for e0, e1 in ev]
+    # ---- eager pass (after the timed region when that one replayed graphs): one rotation of the four stages with a hipEvent
+    # pair around every self-attention launch (all kernel classes with --profile-all) -> `eager` figures and `roofline`
+    eager_step_s = None
+    if use_graph:
+        for st in stage_state:
+            st["sched"].set_timesteps(50, shift=5.0)
+        for i in range(4):
+            one_step(i, eager=True)                         # untimed: eager launch path warm
+        torch.cuda.synchronize()
+        if not args.no_profile:
+            lib.mmpl_profile_enable(1 if args.profile_all else ((1 << 1) << 1))
+        n_eager = 8
+        eev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_eager)]
+        for i in range(n_eager):
+            eev[i][0].record()
+            one_step(i, eager=True)
+            eev[i][1].record()
+        torch.cuda.synchronize()
+        eager_step_s = [e0.elapsed_time(e1) * 1e-3 for e0, e1 in eev]
     prof = None
     if not args.no_profile:
         n = len(KIND_NAMES)
@@ -257,7 +346,12 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = n_lanes * 21.0 / chunk_s
+        # One video: chunk c+1 starts when chunk c's anchor stage is done, and chunks >= 2 consist of that stage and the two
+        # in-fill stages (their first two frames come from the hand-off), so the wavefront keeps at most
+        # (s1 + s2 + s3) / s1 lanes busy (measured stage times of THIS run).
+        occupancy = (stage_s[1] + stage_s[2] + stage_s[3]) / stage_s[1]
+        lanes_busy = min(float(n_lanes), occupancy)
+        value = lanes_busy * 21.0 / chunk_s
         chunk_flops = 102.0 * sum(stage_flops)
         achieved_pf = (2.0 if pair is None else 1.0) * 51.0 * sum(stage_flops) / chunk_s / 1e15    # forwards per rank-step
         res = {
@@ -268,9 +362,13 @@ def main():
                                    f"rotating the four {args.mode.upper()} denoise stages {stage_shapes} (query, attended frames); one "
                                    f"21-latent-frame chunk per GPU = 204 step-equivalents",
                        "frame_seqlen": S, "latent_hw": [lat_h, lat_w], "sampling_steps": 50, "guidance_scale": 5.0,
+                       "timed_path": ("one hipGraph replay per denoise step (2 DiT forwards + fused CFG/UniPC, device-resident step tables)"
+                                      if use_graph else "eager launches"),
                        "parallelism": (f"chunk-per-rank x{world}" if pair is None else f"{n_lanes} chunk lanes x 2 (cond|uncond) CFG split, "
                                        "per-step 2-rank all-gather of flow predictions") +
-                                      (" + RCCL p2p anchor hand-off lane->lane+1" if world > 1 else "")},
+                                      (" + RCCL p2p anchor hand-off lane->lane+1" if world > 1 else "") +
+                                      (f"; one video keeps min(lanes, (s1+s2+s3)/s1 = {occupancy:.2f}) = {lanes_busy:.2f} lanes busy" if world > 1 else "")},
+            "value_independent_chunks": n_lanes * 21.0 / chunk_s,
             "sec_per_denoise_step": elapsed / args.steps,
             "sec_per_denoise_step_by_stage": stage_s,
             "sec_per_chunk_extrapolated": chunk_s,
@@ -278,24 +376,31 @@ def main():
             "mfma_frac_whole_step": achieved_pf * 1e3 / MFMA_PEAK_TFLOPS,
             "vae_decode_s_per_chunk": vae_s,
         }
+        if eager_step_s is not None:
+            e_stage, e_chunk = assemble_chunk_seconds(eager_step_s, 0, stage_flops)
+            res["eager"] = {"sec_per_denoise_step_by_stage": e_stage, "sec_per_chunk_extrapolated": e_chunk,
+                            "latent_frames_per_sec": 21.0 / e_chunk, "steps": len(eager_step_s),
+                            "note": "same steps as plain launches (per-kernel hipEvent pairs on), run right after the timed graph replays"}
         if prof and "attn_self" in prof:
             a = prof["attn_self"]
             ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
             traffic, traffic_src = None, None
-            pmc = os.path.join(ROOT, "profiles", "r01f_pmc_attention_hbm.json")
+            pmc = os.path.join(ROOT, "profiles", "r02_pmc_attention_hbm.json")
             if args.model == "14B" and args.res == "720p" and os.path.exists(pmc):
                 # HBM bytes per launch cannot be collected inside this process (rocprofv3 --pmc wraps the program): the
                 # committed PMC passes of the same kernel on the same four launch shapes, averaged over the rotation
                 st = json.load(open(pmc))["stages"]
                 traffic = sum(st[k]["hbm_bytes"] for k in ("s0", "s1", "s2", "s3")) / 4.0
-                traffic_src = "profiles/r01f_pmc_attention_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, mean of s0..s3)"
-            res["roofline"] = {"bound": "mfma", "kernel": "attn_pp_kernel (self-attention over the KV-slot page table; one op = main launch + split-KV tail launch + merge)",
+                traffic_src = "profiles/r02_pmc_attention_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the shipping kernel, mean of s0..s3)"
+            res["roofline"] = {"bound": "mfma", "kernel": "attn_w64_kernel (self-attention over the KV-slot page table; one op = main launch + split-KV tail launch + merge)",
+                               "measured_in": ("eager pass right after the timed graph replays (hipEvent pair per launch on the launch stream)"
+                                               if use_graph else "timed region (hipEvent pair per launch on the launch stream)"),
                                "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
                                "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
                                "avg_launch_ms": a["ms"] / a["launches"], "launches": a["launches"],
                                "algorithmic_flops_per_launch": a["flops"] / a["launches"]}
             # share of the timed wall clock spent in the roofline kernel (per rank; exact, unlike a share of timed kernels)
-            res["roofline"]["time_share_of_step"] = round(a["ms"] * 1e-3 / sum(step_s), 4)
+            res["roofline"]["time_share_of_step"] = round(a["ms"] * 1e-3 / sum(eager_step_s if eager_step_s is not None else step_s), 4)
             if args.profile_all:
                 tot = sum(v["ms"] for v in prof.values())
                 res["kernel_time_share"] = {k: round(v["ms"] / tot, 4) for k, v in prof.items()}
@@ -304,7 +409,7 @@ def main():
                 res["gemm_tflops"] = g["flops"] / (g["ms"] * 1e-3) / 1e12
         if not args.no_cpu_baseline and world == 1:
             try:
-                res["cpu_baseline"] = cpu_baseline(cfg, lat_h, lat_w, chunk_flops)
+                res["cpu_baseline"] = cpu_baseline(cfg, lat_h, lat_w, stage_shapes, args.cpu_budget_s)
             except Exception as e:  # the baseline is a reported extra; never lose the GPU measurement over it
                 res["cpu_baseline"] = {"value": None, "unit": "latent-frames/s", "cores": torch.get_num_threads(), "kind": "port",
                                        "sample": f"failed: {e!r}"}

@@ -63,7 +63,10 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        import datetime
+        # ChunkHandoff.recv / CfgPair.broadcast park a rank until the previous lane has finished its anchor stage: minutes per
+        # lane at 14B/720p, far beyond the 10-minute default watchdog once there are more than a few lanes
+        dist.init_process_group("nccl", timeout=datetime.timedelta(hours=12))
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     torch.set_grad_enabled(False)
@@ -95,8 +98,8 @@ def main(argv=None):
         px = ((px - 0.5) / 0.5).unsqueeze(0).unsqueeze(2).to(device=dev, dtype=torch.bfloat16)      # [1, 3, 1, H, W]
         image_latent = pipe.vae.encode_to_latent(px).to(torch.bfloat16)                                # [1, 1, 16, h, w]
     if args.checkpoint_path:
-        sd = torch.load(args.checkpoint_path, map_location="cpu")
-        pipe.generator_cond.load_state_dict(sd["generator" if not args.use_ema else "generator_ema"])
+        from .checkpoints import read_mmpl_checkpoint
+        pipe.generator_cond.load_state_dict(read_mmpl_checkpoint(args.checkpoint_path, use_ema=args.use_ema))
 
     if args.data_path:
         from .utils.dataset import TextDataset

@@ -302,6 +302,8 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
   HIP_TRY(mmpl_launch_modulation(h->G(G_HEAD_MOD), 0, w.e, d, 1, w.emod_head, 1, nF, 2, d, s), "head modulation");
 
   const float scale = 1.0f / sqrtf(128.0f);
+  const int self_variant = mmpl_attention_self_variant();
+  const bool prescale_q = self_variant == ATTN_W64;         // fold scale * log2(e) into q before it is rounded (kernels.h)
   const size_t layer_stride = (size_t)n_slots * S * d;
   for (int l = 0; l < c.num_layers; ++l) {
     const bf16_t* em = w.emod + (size_t)l * nF * 6 * d;  // [nF][6][d]
@@ -328,6 +330,7 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
       QkNormArgs a = {};
       a.q = w.big; a.ldq = 3 * d; a.k = w.big + d; a.ldk = 3 * d; a.v = nullptr; a.ldv = 3 * d;
       a.wq = h->Lw(l, L_NQ); a.wk = h->Lw(l, L_NK); a.rows = Lq; a.d = d; a.eps = c.eps; a.rope = 1;
+      a.q_scale = prescale_q ? scale * 1.4426950408889634f : 0.f;
       a.cos_tab = h->cos_tab; a.sin_tab = h->sin_tab; a.rows_per_frame = S; a.grid_w = h->gw;
       for (int i = 0; i < nF; ++i) {
         a.frame_ids[i] = frame_ids[i];
@@ -351,6 +354,8 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
           a.v_pages[np] = w.vsc + (size_t)i * S * d;
         }
       a.n_pages = np;
+      a.variant = self_variant;
+      a.q_prescaled = prescale_q;
       a.split_ws = (float*)w.xn;                    // norm1's output is dead once the QKV GEMM has consumed it
       a.split_ws_bytes = (size_t)Lq * d * sizeof(bf16_t);
       ProfScope ps(K_ATTN_SELF, 4.0 * Lq * (double)np * S * d, s);
@@ -405,9 +410,10 @@ int mmpl_attn_fwd_variant(const void* q, int ldq, void* o, int ldo, const void* 
                           int ldk, int ldv, int n_pages, int page_rows, int Lq, int num_heads, float softmax_scale,
                           void* workspace, size_t workspace_bytes, int variant, int cross, mmpl_stream_t stream) {
   if (n_pages < 1 || n_pages > MMPL_MAX_PAGES) return fail("mmpl_attn_fwd", "n_pages out of range");
-  if (variant < ATTN_AUTO || variant > ATTN_W64) return fail("mmpl_attn_fwd", "unknown kernel variant");
+  if (variant < ATTN_AUTO || variant > ATTN_W64 + 1) return fail("mmpl_attn_fwd", "unknown kernel variant");
   AttnArgs a = {};
-  a.variant = variant;
+  a.variant = variant > ATTN_W64 ? ATTN_W64 : variant;
+  a.q_prescaled = variant == ATTN_W64 + 1;
   a.cross = cross != 0;
   a.q = (const bf16_t*)q; a.ldq = ldq; a.o = (bf16_t*)o; a.ldo = ldo; a.ldk = ldk; a.ldv = ldv; a.n_pages = n_pages;
   a.page_rows = page_rows; a.Lq = Lq; a.H = num_heads; a.scale = softmax_scale;

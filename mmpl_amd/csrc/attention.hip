@@ -605,19 +605,32 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnArgs a, int local_b
 
 size_t mmpl_attention_split_ws_bytes() { return (size_t)256 * QB * 130 * sizeof(float); }   // <= one block per CU in the tail round
 
+namespace {
+bool env_flag(const char* name) { const char* v = getenv(name); return v && atoi(v); }
+}  // namespace
+
+// MMPL_ATTN_V1=1 / MMPL_ATTN_PP=1: A/B runs of a whole forward on the lock-step / ping-pong kernel (read once per process)
+int mmpl_attention_self_variant() {
+  static const int v = env_flag("MMPL_ATTN_V1") ? ATTN_LOCKSTEP : env_flag("MMPL_ATTN_PP") ? ATTN_PINGPONG : ATTN_W64;
+  return v;
+}
+
 hipError_t mmpl_launch_attention(const AttnArgs& a, hipStream_t s) {
   if (a.Lq <= 0) return hipSuccess;
   if (a.n_pages <= 0 || a.n_pages > MMPL_MAX_PAGES || a.page_rows <= 0 || (a.ldq % 8) || (a.ldk % 8) || (a.ldv % 8) ||
       (a.ldo % 4) || a.variant < ATTN_AUTO || a.variant > ATTN_W64)
     return hipErrorInvalidValue;
-  // Kernel choice.  Self-attention over cache pages -> the 64-rows-per-wave kernel (attn_w64.hip); the 8-tile text
-  // cross-attention stays on the lock-step kernel (its prologue is the shortest).  AttnArgs.variant (C ABI:
-  // mmpl_attn_fwd_variant) or, for A/B runs of a whole forward, MMPL_ATTN_V1=1 / MMPL_ATTN_PP=1 select another one.
-  static const bool env_v1 = getenv("MMPL_ATTN_V1") && atoi(getenv("MMPL_ATTN_V1"));
-  static const bool env_pp = getenv("MMPL_ATTN_PP") && atoi(getenv("MMPL_ATTN_PP"));
-  static const bool no_split = getenv("MMPL_ATTN_NOSPLIT") && atoi(getenv("MMPL_ATTN_NOSPLIT"));
+  // Kernel choice.  The DiT forward's self-attention (q prescaled by its producer) -> the 64-rows-per-wave kernel
+  // (attn_w64.hip); the 8-tile text cross-attention -> the lock-step kernel (its prologue is the shortest); a raw-q launch
+  // (the attention() seam) -> the ping-pong kernel (see mmpl_attention_self_variant).  AttnArgs.variant (C ABI:
+  // mmpl_attn_fwd_variant) selects one explicitly.
+  static const bool no_split = env_flag("MMPL_ATTN_NOSPLIT");
   int variant = a.variant;
-  if (variant == ATTN_AUTO) variant = a.cross || env_v1 ? ATTN_LOCKSTEP : env_pp ? ATTN_PINGPONG : ATTN_W64;
+  if (variant == ATTN_AUTO) {
+    variant = a.cross ? ATTN_LOCKSTEP : mmpl_attention_self_variant();
+    if (variant == ATTN_W64 && !a.q_prescaled) variant = ATTN_PINGPONG;
+  }
+  if (a.q_prescaled && variant != ATTN_W64) return hipErrorInvalidValue;
   const int n_qb = (a.Lq + QB - 1) / QB;
   if (variant == ATTN_LOCKSTEP) {
     const void* f = a.cross ? reinterpret_cast<const void*>(attn_fwd_kernel<1>) : reinterpret_cast<const void*>(attn_fwd_kernel<0>);

@@ -304,8 +304,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   asm volatile("s_nop 0" ::: ALL_AGPRS);
   sfor<128>([](auto ii) { asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(AO + decltype(ii)::value)); });
 
-  // ---- Q fragments -> a[128:191], prescaled: lane (l31, hi) holds Q[row][16c + 8*hi .. +8] * scale * log2(e) (rounded to bf16)
+  // ---- Q fragments -> a[128:191], prescaled: lane (l31, hi) holds Q[row][16c + 8*hi .. +8] * scale * log2(e).  The DiT forward
+  // folds that factor into q where q is produced (qknorm_kernel, before the rounding to bf16: q_prescaled); a raw q is scaled
+  // here, at the price of a second rounding.
   const float c = a.scale * 1.4426950408889634f;
+  const float qmul = a.q_prescaled ? 1.0f : c;
   {
     const bf16_t* qbase = a.q + head * 128 + 8 * hi;
 #pragma unroll
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         qf[cc] = *reinterpret_cast<const u32x4*>(qp + 16 * cc);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          qf[cc][j] = pack2bf(__uint_as_float(qf[cc][j] << 16) * c, __uint_as_float(qf[cc][j] & 0xffff0000u) * c);
+          qf[cc][j] = pack2bf(__uint_as_float(qf[cc][j] << 16) * qmul, __uint_as_float(qf[cc][j] & 0xffff0000u) * qmul);
       }
       if (X == 0)
         sfor<32>([&qf](auto ii) { constexpr int i = decltype(ii)::value; asm volatile("v_accvgpr_write_b32 a[%c0], %1" ::"i"(AQ + i), "v"(qf[i >> 2][i & 3])); });

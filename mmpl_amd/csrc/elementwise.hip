@@ -136,6 +136,10 @@ __global__ __launch_bounds__(256) void qknorm_kernel(QkNormArgs a) {
           o[2 * j + 1] = re * sn[j] + im * cs[j];
         }
       }
+      if (which == 0 && a.q_scale != 0.f) {      // softmax scale folded into q while it is still fp32 (attn_w64.hip)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] *= a.q_scale;
+      }
       *reinterpret_cast<uint4*>(dst + ch * 8) = pack8(o);
     }
   }
@@ -237,7 +241,8 @@ MMPL_DEV void unipc_body(const UniPCArgs& a) {
   }
 }
 __global__ void unipc_kernel(UniPCArgs a) { unipc_body(a); }
-__global__ void unipc_table_kernel(UniPCArgs a, const UniPCStepDev* table, const int* step) {
+__global__ void unipc_table_kernel(UniPCArgs a, const UniPCStepDev* table, const int* step, int n_steps) {
+  if (*step >= n_steps) return;          // a replay beyond the uploaded table must not apply garbage coefficients
   const UniPCStepDev st = table[*step];
   a.guidance = st.guidance; a.sigma_cur = st.sigma_cur; a.use_corrector = st.use_corrector; a.corr_order = st.corr_order;
   a.c_c1 = st.c_c1; a.c_c2 = st.c_c2; a.c_c3 = st.c_c3; a.c_inv_rk = st.c_inv_rk; a.c_rho0 = st.c_rho0; a.c_rho_last = st.c_rho_last;
@@ -245,6 +250,7 @@ __global__ void unipc_table_kernel(UniPCArgs a, const UniPCStepDev* table, const
   unipc_body(a);
 }
 __global__ void unipc_advance_kernel(int* step, float* t_out, const float* t_tab, int n_t, int n_steps) {
+  if (*step >= n_steps) return;
   const int nxt = *step + 1;
   __syncthreads();
   if (threadIdx.x == 0) *step = nxt;
@@ -326,7 +332,7 @@ hipError_t mmpl_launch_unipc(const UniPCArgs& a, hipStream_t s) {
 }
 hipError_t mmpl_launch_unipc_table(const UniPCArgs& a, const UniPCStepDev* table, int* step, float* t_out, const float* t_tab,
                                    int n_t, int n_steps, hipStream_t s) {
-  hipLaunchKernelGGL(unipc_table_kernel, dim3(grid_for(a.n)), dim3(256), 0, s, a, table, step);
+  hipLaunchKernelGGL(unipc_table_kernel, dim3(grid_for(a.n)), dim3(256), 0, s, a, table, step, n_steps);
   hipLaunchKernelGGL(unipc_advance_kernel, dim3(1), dim3(64), 0, s, step, t_out, t_tab, n_t, n_steps);
   return hipGetLastError();
 }

@@ -44,9 +44,15 @@ struct AttnArgs {
   float scale;                     // softmax scale (1/sqrt(128))
   int cross;                       // 1: text cross-attention launch (symbol tag only)
   float* split_ws; size_t split_ws_bytes;   // optional scratch for the split-KV tail round (nullptr: never split)
-  int variant;                     // MMPL_ATTN_* kernel selector (0 = auto)
+  int variant;                     // ATTN_* kernel selector (0 = auto)
+  int q_prescaled;                 // q was already multiplied by scale * log2(e) by its producer (ATTN_W64 only)
 };
 enum { ATTN_AUTO = 0, ATTN_LOCKSTEP = 1, ATTN_PINGPONG = 2, ATTN_W64 = 3 };
+// The kernel ATTN_AUTO resolves to for a self-attention launch whose producer can fold the softmax scale into q before q is
+// rounded to bf16 (the DiT forward: qknorm_kernel's q_scale).  ATTN_W64 computes exp2(K.q) without a per-score multiply, so it
+// wants q = bf16(q_fp32 * scale * log2(e)); handing it a bf16 q to prescale itself costs a second rounding of q, which shows
+// on sharp softmax rows (large QK-norm gains) -- a raw-q ATTN_AUTO launch (the attention() seam) therefore takes ATTN_PINGPONG.
+int mmpl_attention_self_variant();
 // attn_w64.hip (4 waves x 64 query rows, one wave per SIMD)
 int mmpl_attention_w64_smem();
 const void* mmpl_attention_w64_symbol(int split);
@@ -75,6 +81,7 @@ struct QkNormArgs {
   const bf16_t* wq; const bf16_t* wk; // RMSNorm gains [d]
   int rows, d;
   float eps;
+  float q_scale;                      // q is multiplied by this after RoPE, before its (single) rounding to bf16; 0 = 1
   int rope;                           // 0: no rope (cross-attn q / context k)
   const float* cos_tab; const float* sin_tab;  // [1024][64] fp32
   int frame_ids[8];                   // temporal rope position per local frame

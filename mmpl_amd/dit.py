@@ -130,10 +130,11 @@ class DitEngine:
         ws = self.workspace(nF) if workspace is None else workspace
         n_slots = k_cache.shape[1] // self.S
         ia = lambda v: (C.c_int * len(v))(*[int(i) for i in v])
-        _lib.check(self._lib.mmpl_dit_forward(
-            self._h, _lib.ptr(x), _lib.ptr(t), nF, ia(frame_ids), ia(write_slots), ia(visible_slots), len(visible_slots),
-            _lib.ptr(k_cache), _lib.ptr(v_cache), n_slots, _lib.ptr(cross_k), _lib.ptr(cross_v), _lib.ptr(out), _lib.ptr(ws),
-            ws.numel(), _lib.stream_ptr()), "mmpl_dit_forward")
+        with torch.cuda.device(self.device):          # the stream handed to the library is this device's current stream
+            _lib.check(self._lib.mmpl_dit_forward(
+                self._h, _lib.ptr(x), _lib.ptr(t), nF, ia(frame_ids), ia(write_slots), ia(visible_slots), len(visible_slots),
+                _lib.ptr(k_cache), _lib.ptr(v_cache), n_slots, _lib.ptr(cross_k), _lib.ptr(cross_v), _lib.ptr(out), _lib.ptr(ws),
+                ws.numel(), _lib.stream_ptr()), "mmpl_dit_forward")
         return out
 
     # ------------------------------------------------------------------ hipGraph

@@ -153,7 +153,9 @@ class FlowUniPCMultistepScheduler:
     # -- device-resident step table: one hipGraph per denoise step, replayed with no host work in between --------------
     def build_step_table(self, guidance: float, device) -> None:
         """Upload the scalars of ALL remaining steps (they depend only on the step index, never on data) plus the timestep
-        of every step; `step_cfg_table` then reads entry *counter on the device.  Host bookkeeping is advanced to the end."""
+        of every step; `step_cfg_table` then reads entry *counter on the device.  The host-side step bookkeeping of THIS
+        object is not advanced (the scalars come from a copy): after the table's last step the device kernel does nothing
+        (the counter is clamped), `reset_step_table` rewinds it for another pass over the same schedule."""
         import copy
         probe = copy.copy(self)
         probe._state = None
@@ -166,6 +168,14 @@ class FlowUniPCMultistepScheduler:
         self._t_table = torch.tensor([float(t) for t in self.timesteps[self.step_index:]], dtype=torch.float32, device=device)
         self._counter = torch.zeros(1, dtype=torch.int32, device=device)
         self._table_n = n
+
+    def reset_step_table(self, timestep: torch.Tensor) -> None:
+        """Rewind the device step counter, the solver history and `timestep` to the first entry of the uploaded table."""
+        self._counter.zero_()
+        if self._state is not None:
+            for t in self._state:
+                t.zero_()
+        timestep.fill_(float(self._t_table[0]))
 
     def step_cfg_table(self, flow_cond: torch.Tensor, flow_uncond: torch.Tensor, sample: torch.Tensor, timestep: torch.Tensor) -> None:
         """CFG combine + scheduler step with device-resident scalars (capturable: no host value enters the launch);

@@ -11,7 +11,6 @@ into ONE allocation per cache that the HIP forward addresses through its slot ta
 """
 from __future__ import annotations
 
-import json
 import os
 from typing import Dict, List, Optional
 
@@ -86,42 +85,29 @@ class WanFPSWrapper(torch.nn.Module):
         super().__init__()
         assert is_causal, "only the causal FPS generator is on the hot path"
         self.geometry = geometry or Geometry.named("480p")
+        from .checkpoints import read_diffusers_dir
         cfg = model_config
         wdir = f"{local_wan_path}/{model_name}/"
-        if cfg is None and os.path.exists(os.path.join(wdir, "config.json")):
-            with open(os.path.join(wdir, "config.json")) as f:
-                j = json.load(f)
-            cfg = dict(dim=j["dim"], ffn_dim=j["ffn_dim"], num_heads=j["num_heads"], num_layers=j["num_layers"],
-                       text_dim=j.get("text_dim", 4096), freq_dim=j.get("freq_dim", 256))
+        disk_cfg, disk_sd = read_diffusers_dir(wdir)          # CausalFPSWanModel.from_pretrained(...) (wan_wrapper.py:328-330)
+        if cfg is None:
+            cfg = disk_cfg
         if cfg is None:
             key = "14B" if "14B" in model_name else "1.3B"
             cfg = WAN_CONFIGS[key]
         self.engine = DitEngine(cfg, self.geometry.lat_h, self.geometry.lat_w, device)
         self.model = _ModelHandle(self.engine)
-        self._maybe_load_pretrained(wdir)
+        if disk_sd is not None:
+            self.engine.load_state_dict(disk_sd)
         self.uniform_timestep = not is_causal
         self.scheduler = FlowMatchScheduler(shift=timestep_shift, sigma_min=0.0, extra_one_step=True)
         self.scheduler.set_timesteps(1000, training=True)
         self.seq_len = self.geometry.frame_seqlen * self.geometry.frames_per_chunk
 
-    def _maybe_load_pretrained(self, wdir: str):
-        """diffusers-style dir: config.json + diffusion_pytorch_model*.safetensors."""
-        if not os.path.isdir(wdir):
-            return
-        files = sorted(f for f in os.listdir(wdir) if f.startswith("diffusion_pytorch_model") and f.endswith(".safetensors"))
-        if not files:
-            return
-        from safetensors.torch import load_file
-        sd: Dict[str, torch.Tensor] = {}
-        for f in files:
-            sd.update(load_file(os.path.join(wdir, f)))
-        self.engine.load_state_dict(sd)
-
     # nn.Module-compatible entry points the entry scripts use
     def load_state_dict(self, state_dict, strict: bool = True):
         """MMPL .pt checkpoints hold {'generator': {'model.<key>': tensor}} (Wan_fps_inference_1gpu.py:66-68)."""
-        prefix = "model." if any(k.startswith("model.") for k in state_dict) else ""
-        self.engine.load_state_dict(state_dict, prefix=prefix)
+        from .checkpoints import strip_generator_prefix
+        self.engine.load_state_dict(strip_generator_prefix(state_dict))
         return torch.nn.modules.module._IncompatibleKeys([], [])
 
     def to(self, *args, **kwargs):
@@ -212,11 +198,12 @@ class WanTextEncoder(torch.nn.Module):
             return
         path = pretrained_path or f"{local_wan_path}/Wan2.1-T2V-14B/models_t5_umt5-xxl-enc-bf16.pth"
         if state_dict is None and os.path.exists(path):
-            state_dict = torch.load(path, map_location="cpu", weights_only=False)
+            from .checkpoints import read_state_dict
+            state_dict = read_state_dict(path)
         if state_dict is not None:
-            from .synthetic import T5_CONFIGS
+            from .checkpoints import infer_t5_config
             from .t5 import T5Engine
-            self.model = T5Engine(cfg or T5_CONFIGS["umt5-xxl"], text_len=text_len, device=device)
+            self.model = T5Engine(cfg or infer_t5_config(state_dict), text_len=text_len, device=device)
             self.model.load_state_dict(state_dict)
 
     def to(self, *args, **kwargs):
@@ -287,7 +274,8 @@ class WanVAEWrapper(torch.nn.Module):
         self.model = VaeEngine(self.geometry.lat_h, self.geometry.lat_w, device)
         path = pretrained_path or f"{local_wan_path}/Wan2.1-T2V-14B/Wan2.1_VAE.pth"
         if state_dict is None and os.path.exists(path):
-            state_dict = torch.load(path, map_location="cpu")
+            from .checkpoints import read_state_dict
+            state_dict = read_state_dict(path)
         if state_dict is not None:
             self.model.load_state_dict(state_dict)
 

@@ -78,3 +78,14 @@ def test_device_table_step_equals_host_scalar_step():
         b.step_cfg_table(fc, fu, xb, t)
         assert torch.equal(xa, xb), i
     assert int(b._counter.item()) == 50
+    # a replay beyond the uploaded table is a no-op (no out-of-bounds coefficients, counter stays clamped) ...
+    keep = xb.clone()
+    b.step_cfg_table(flows[0][0], flows[0][1], xb, t)
+    assert torch.equal(xb, keep) and int(b._counter.item()) == 50
+    # ... and a rewind replays the same trajectory bit-identically
+    b.reset_step_table(t)
+    xb = x0.clone()
+    assert int(b._counter.item()) == 0 and float(t[0]) == float(b.timesteps[0])
+    for fc, fu in flows:
+        b.step_cfg_table(fc, fu, xb, t)
+    assert torch.equal(xa, xb)

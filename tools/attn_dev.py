@@ -3,7 +3,7 @@
 
     python tools/attn_dev.py check [variants...]     # edge-case shapes vs an fp32 restatement evaluated by torch on the device
     python tools/attn_dev.py bench [variants...]     # 14B/720p stage shapes, interleaved rounds, TFLOP/s per variant
-variants: 1 lock-step, 2 ping-pong, 3 w64 (default: 2 3)
+variants: 1 lock-step, 2 ping-pong, 3 w64 on a raw q, 4 w64 on a producer-prescaled q (default: 2 4)
 """
 import ctypes as C
 import math
@@ -24,6 +24,9 @@ WS = torch.empty(lib.mmpl_attn_workspace_bytes(), dtype=torch.uint8, device=dev)
 def run(variant, q, ldq, o, d, kp, vp, n_pages, S, Lq, H, ws=True):
     _lib.check(lib.mmpl_attn_fwd_variant(_lib.ptr(q), ldq, _lib.ptr(o), d, kp, vp, d, d, n_pages, S, Lq, H, 1.0 / math.sqrt(128),
                                          _lib.ptr(WS) if ws else None, WS.numel() if ws else 0, variant, 0, _lib.stream_ptr()))
+
+
+CQ = (1.0 / math.sqrt(128)) * 1.4426950408889634
 
 
 def ref_fp32(q, k, v, H):
@@ -48,7 +51,9 @@ def check(variants):
         torch.manual_seed(Lq + S)
         d = H * 128
         ldm = 3 if H == 2 else 1
-        q = torch.randn(Lq, ldm * d, device=dev).to(BF)
+        q32 = torch.randn(Lq, ldm * d, device=dev)
+        q = q32.to(BF)
+        qp = (q32 * CQ).to(BF)                       # variant 4: scale folded in before the rounding
         n_slots = n_pages + 2
         kc = torch.randn(n_slots * S, d, device=dev).to(BF)
         vc = torch.randn(n_slots * S, d, device=dev).to(BF)
@@ -56,12 +61,13 @@ def check(variants):
         kp = (C.c_void_p * n_pages)(*[kc[s * S:].data_ptr() for s in slots])
         vp = (C.c_void_p * n_pages)(*[vc[s * S:].data_ptr() for s in slots])
         idx = torch.cat([torch.arange(s * S, (s + 1) * S) for s in slots]).to(dev)
-        ref = ref_fp32(q[:, :d], kc[idx], vc[idx], H)
+        refs = {False: ref_fp32(q[:, :d], kc[idx], vc[idx], H), True: ref_fp32(qp[:, :d].float() / CQ, kc[idx], vc[idx], H)}
         line = f"Lq={Lq} H={H} S={S} pages={n_pages}:"
         for var in variants:
             o = torch.full((Lq, d), float("nan"), device=dev, dtype=BF)
-            run(var, q, ldm * d, o, d, kp, vp, n_pages, S, Lq, H)
+            run(var, qp if var == 4 else q, ldm * d, o, d, kp, vp, n_pages, S, Lq, H)
             torch.cuda.synchronize()
+            ref = refs[var == 4]
             e = rel_l2(o, ref) if torch.isfinite(o.float()).all() else float("nan")
             line += f"  v{var} {e:.2e}"
             if not (e < 1e-2):
@@ -79,11 +85,12 @@ def check(variants):
     k[200] = (q[40].float() * 30).to(BF)          # far beyond any deferral threshold
     kp = (C.c_void_p * 1)(k.data_ptr())
     vp = (C.c_void_p * 1)(v.data_ptr())
-    ref = ref_fp32(q, k, v, 1)
+    qp = (q.float() * CQ).to(BF)
     for var in variants:
         o = torch.full((Lq, 128), float("nan"), device=dev, dtype=BF)
-        run(var, q, 128, o, 128, kp, vp, 1, S, Lq, 1)
+        run(var, qp if var == 4 else q, 128, o, 128, kp, vp, 1, S, Lq, 1)
         torch.cuda.synchronize()
+        ref = ref_fp32(qp.float() / CQ if var == 4 else q, k, v, 1)
         e, m = rel_l2(o, ref), (o.float() - ref).abs().max().item()
         tol = 2.0 ** -7 * ref.abs().max().item()       # 2 bf16 ulps of the largest output
         print(f"spiked: v{var} rel {e:.2e} max {m:.2e}" + ("" if e < 1e-2 and m < tol else " <-- BAD"), flush=True)
@@ -132,7 +139,7 @@ def bench(variants, iters=3, rounds=3, stages=("s0", "s1", "s2", "s3")):
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "check"
-    variants = [int(x) for x in sys.argv[2:] if x.isdigit()] or [2, 3]
+    variants = [int(x) for x in sys.argv[2:] if x.isdigit()] or [2, 4]
     stages = [x.split("=")[1].split(",") for x in sys.argv[2:] if x.startswith("stages=")]
     if what == "check":
         sys.exit(1 if check(variants) else 0)
