@@ -42,7 +42,6 @@ constexpr int W64_SMEM = 2 * RING * TILE;
 constexpr float BOUND_FAST = 1.2089258e24f;                            // 2^80
 constexpr float BOUND_GEN = 1073741824.f;                              // 2^30
 constexpr float FIRST_RANGE = 64.f;
-constexpr int DMA_BIAS = 4096;                                         // keeps "row offset - LDS piece offset" non-negative
 
 template <int I> using ic = std::integral_constant<int, I>;
 template <class F, int... I> MMPL_DEV void sfor_(F&& f, std::integer_sequence<int, I...>) { (f(ic<I>{}), ...); }
@@ -56,6 +55,12 @@ template <int N, class F> MMPL_DEV void sfor(F&& f) { sfor_(f, std::make_integer
 
 constexpr int AO = 0, AQ = 128, AV = 192;      // accumulator-file map
 
+// Timing ablations for tools/w64_sweep.sh (results are garbage): -DW64_ABL=<bits>  1 no LDS-DMA in the loop, 2 no softmax,
+// 4 no fragment reads, 8 no barrier / waits.  0 in every shipped build.
+#ifndef W64_ABL
+#define W64_ABL 0
+#endif
+
 // All state of a wave.  Passed by reference through always-inlined members, so every field ends up in a register (VGPR or,
 // when provably wave-uniform, SGPR); arrays are only ever indexed with compile-time constants.
 struct Ctx {
@@ -66,17 +71,20 @@ struct Ctx {
   float l[2], mref[2];   // running row sum (this lane's 32 kv columns of every tile) and reference (log2 units)
   float la[2], lb[2];    // the tile's partial sums (even / odd register of each pair)
   float t[2][2][2];      // exp results in flight: [stream][pair parity][element]
-  uint32_t dko[4], dvo[4];   // per-piece LDS-DMA source offsets of the tile under the K / V cursor
+  uint32_t dko[4], dvo[4];   // per-piece LDS-DMA source offsets within a tile (constant)
   uint32_t kbase, vbase, kaddr, vaddr[4];
   int hi;
   // ---- wave-uniform state
   const bf16_t* const* k_pages; const bf16_t* const* v_pages;
   int ldk, ldv, page_rows, head, T;
-  const bf16_t* kptr; const bf16_t* vptr;      // cursor tile's first row, this head, minus DMA_BIAS bytes
-  int krow0, kpg, kt, vrow0, vpg, vt;          // cursors: row within page, page, tile index within the block
+  u32x4 ksrd, vsrd;                            // buffer descriptors of the cursors' pages (this head's 256-byte column)
+  uint32_t ksoff, vsoff, tile_bytes_k, tile_bytes_v;   // byte offset of the cursor tile's first row within its page
+  int kpg, kt, vpg, vt;                        // cursors: page, tile index within the block
+  int kplain, vplain;                          // advances left before the cursor leaves its page or meets the block's end
+  int t_first, tiles_pp;
   uint32_t kslot, vslot;                       // LDS address of this wave's piece 0 in the slot the cursor tile goes to
   uint32_t rk, rv;                             // ring offsets of the tiles the next B phase reads (K(j+1), V(j))
-  int crow[2];                                 // first kv row (within its page) of the tile each stream is at
+  int mleft[2];                                // tiles before the next ragged one (a page's last) of each softmax stream
   int first[2];                                // stream has not finished its first tile yet
   int gen;                                     // wave is in GENERAL mode
   int prow, drow, dchunk;
@@ -95,12 +103,14 @@ struct Ctx {
                  "v"(P[X][ks]));
   }
   // ---------------------------------------------------------------- LDS fragment reads
-  MMPL_DEV void addr_k() { asm volatile("v_add_u32 %0, %1, %2" : "=v"(kaddr) : "s"(rk), "v"(kbase)); }
+  MMPL_DEV void addr_k() { if constexpr (W64_ABL & 4) return; asm volatile("v_add_u32 %0, %1, %2" : "=v"(kaddr) : "s"(rk), "v"(kbase)); }
   MMPL_DEV void addr_v() {
+    if constexpr (W64_ABL & 4) return;
     asm volatile("v_add_u32 %0, %4, %5\n\tv_xor_b32 %1, 64, %0\n\tv_xor_b32 %2, 0x80, %0\n\tv_xor_b32 %3, 0xc0, %0"
                  : "=&v"(vaddr[0]), "=&v"(vaddr[1]), "=&v"(vaddr[2]), "=&v"(vaddr[3]) : "s"(rv), "v"(vbase));
   }
   template <int G> MMPL_DEV void lds_k() {               // fragment G = (chunk, half); the chunk enters the address by XOR
+    if constexpr (W64_ABL & 4) return;
     constexpr int off = (G & 1) * 32 * 256, cs = G >> 1;
     if constexpr ((G & 1) == 0 && G > 0)
       asm volatile("v_xor_b32 %1, %2, %1\n\tds_read_b128 %0, %1 offset:%c3" : "=v"(kf[G]), "+v"(kaddr) : "i"((32 * cs) ^ (32 * (cs - 1))), "i"(off));
@@ -108,79 +118,95 @@ struct Ctx {
       asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(kf[G]) : "v"(kaddr), "i"(off));
   }
   template <int G> MMPL_DEV void lds_v() {               // fragment G = (ks, nb) -> a[192 + 4G ..]
+    if constexpr (W64_ABL & 4) return;
     constexpr int va = AV + 4 * G, off = (G >> 2) * 16 * 256;
     asm volatile("ds_read_b64_tr_b16 a[%c1:%c2], %0 offset:%c3\n\tds_read_b64_tr_b16 a[%c4:%c5], %0 offset:%c6" ::"v"(vaddr[G & 3]),
                  "i"(va), "i"(va + 1), "i"(off), "i"(va + 2), "i"(va + 3), "i"(off + 8 * 256));
   }
-  template <int N> MMPL_DEV void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%c0)" ::"i"(N) : "memory"); }
-  MMPL_DEV void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+  template <int N> MMPL_DEV void wait_lgkm() { if constexpr (W64_ABL & 8) return; asm volatile("s_waitcnt lgkmcnt(%c0)" ::"i"(N) : "memory"); }
+  MMPL_DEV void wait_lgkm0() { if constexpr (W64_ABL & 8) return; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
   // K(j+1) and V(j) (DMA events j-3 and j-2) have landed when at most the 8 pieces of event j-1 are outstanding; all of this
   // wave's fragment reads of the slots event j is about to overwrite are complete (lgkmcnt 0)
-  MMPL_DEV void barrier() { asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+  MMPL_DEV void barrier() { if constexpr (W64_ABL & 8) return; asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
   // ---------------------------------------------------------------- LDS-DMA (event j = { K(j+4), V(j+2) })
-  // A piece = 4 rows x 256 B = one global_load_lds_dwordx4.  Wave w moves pieces 4w..4w+3 of a tile; M0 (the LDS destination
-  // of piece 4w) is written once per tile and the instruction offset -- which the hardware adds to BOTH addresses -- steps
-  // the LDS side by 1 KiB per piece; the per-piece source offsets are pre-compensated (- 1024 k + DMA_BIAS, bias taken out of
-  // the base pointer).  Nothing the compiler emits in this kernel touches M0 (audited in the .s: no other m0 write).
+  // A piece = 4 rows x 256 B = one buffer_load_dwordx4 ... lds.  Wave w moves pieces 4w..4w+3 of a tile; M0 (the LDS
+  // destination of piece 4w) is written once per tile and the instruction offset -- which the hardware adds to BOTH addresses
+  // -- steps the LDS side by 1 KiB per piece (the per-piece source offsets are pre-compensated by - 1024 k).  The source is
+  // a buffer descriptor over the cursor's PAGE (base = page + this head's column, num_records ends inside the page's last
+  // row) plus the tile's byte offset in the scalar offset: rows past the end of the page fail the hardware range check
+  // (voffset + soffset + inst_offset >= num_records) and arrive in LDS as ZEROS -- a page's ragged last tile needs no
+  // clamped addresses (tools/probe_bufdma.hip: semantics verified on MI355X).  Nothing the compiler emits in this kernel
+  // touches M0 (tests/test_isa_audit.py).  Piece 0's "s_mov m0 + s_nop 3" is also the 5 wait states gfx9 wants between a
+  // scalar write of the offset / descriptor registers (the cursor advance, which hipcc may place right before this asm
+  // without knowing what is inside it) and the VMEM instruction that reads them.
   template <int K> MMPL_DEV void dma_k() {
+    if constexpr (W64_ABL & 1) return;
     if constexpr (K == 0)
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(dko[0]), "s"(kptr), "s"(kslot) : "memory");
+      asm volatile("s_mov_b32 m0, %3\n\ts_nop 3\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(dko[0]), "s"(ksrd), "s"(ksoff), "s"(kslot) : "memory");
     else
-      asm volatile("global_load_lds_dwordx4 %0, %1 offset:%c2" ::"v"(dko[K]), "s"(kptr), "i"(1024 * K) : "memory");
+      asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:%c3 lds" ::"v"(dko[K]), "s"(ksrd), "s"(ksoff), "i"(1024 * K) : "memory");
   }
   template <int K> MMPL_DEV void dma_v() {
+    if constexpr (W64_ABL & 1) return;
     if constexpr (K == 0)
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(dvo[0]), "s"(vptr), "s"(vslot) : "memory");
+      asm volatile("s_mov_b32 m0, %3\n\ts_nop 3\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(dvo[0]), "s"(vsrd), "s"(vsoff), "s"(vslot) : "memory");
     else
-      asm volatile("global_load_lds_dwordx4 %0, %1 offset:%c2" ::"v"(dvo[K]), "s"(vptr), "i"(1024 * K) : "memory");
+      asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:%c3 lds" ::"v"(dvo[K]), "s"(vsrd), "s"(vsoff), "i"(1024 * K) : "memory");
   }
-  // source offsets of the four pieces for a tile with `lim` + 1 valid rows (63: full tile; less: a page's ragged last tile,
-  // rows clamped to the last valid one and masked in the softmax).  The bank swizzle is keyed on the LDS row, not the source row.
-  MMPL_DEV void set_k_offsets(int lim) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      dko[k] = (uint32_t)(min(prow + 4 * k, lim) * ldk + ((dchunk ^ ((prow + 4 * k) & 15)) << 3)) * 2u + (DMA_BIAS - 1024 * k);
-  }
-  MMPL_DEV void set_v_offsets(int lim) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      dvo[k] = (uint32_t)(min(prow + 4 * k, lim) * ldv + ((dchunk ^ (drow << 2)) << 3)) * 2u + (DMA_BIAS - 1024 * k);
+  MMPL_DEV static u32x4 page_srd(const bf16_t* page, int head_, int rows, int ld) {
+    const uint64_t p = (uint64_t)(page + head_ * 128);
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((uint32_t)p);
+    r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32) & 0xffffu);
+    r[2] = __builtin_amdgcn_readfirstlane((uint32_t)rows * (uint32_t)ld * 2u - ((uint32_t)ld * 2u - 256u));
+    r[3] = 0x00020000u;
+    return r;
   }
   // Cursors stop on the block's last tile (it is simply re-fetched), so every event issues exactly 8 pieces and the counted
-  // waits never change.
+  // waits never change.  The common advance -- next tile exists and lies in the same page -- is three SALU instructions
+  // behind ONE not-taken branch (a countdown); page switches and the block's end take the out-of-line path.
+  MMPL_DEV int plain_run(int t) const {                // advances from tile t (block-relative) that stay in its page and in the block
+    const int pos = (t_first + t) % tiles_pp;
+    return __builtin_amdgcn_readfirstlane(max(min(tiles_pp - 1 - pos, T - 1 - t), 0));
+  }
   MMPL_DEV void advance_k() {
     kslot = (kslot + TILE) & (RING * TILE - 1);
-    if (kt + 1 < T) {
+    if (__builtin_expect(kplain > 0, 1)) {
+      --kplain;
       ++kt;
-      const bool was_ragged = krow0 + KVB > page_rows;
-      krow0 += KVB;
-      kptr += (size_t)KVB * ldk;
-      if (krow0 >= page_rows) {
-        krow0 = 0;
+      ksoff += tile_bytes_k;
+    } else if (kt + 1 < T) {
+      ++kt;
+      if ((t_first + kt) % tiles_pp == 0) {
         ++kpg;
-        kptr = k_pages[kpg] + head * 128 - DMA_BIAS / 2;
+        ksrd = page_srd(k_pages[kpg], head, page_rows, ldk);
+        ksoff = 0;
+      } else {
+        ksoff += tile_bytes_k;
       }
-      if (was_ragged || krow0 + KVB > page_rows) set_k_offsets(min(KVB - 1, page_rows - 1 - krow0));
+      kplain = plain_run(kt);
     }
-    asm volatile("" : "+s"(kptr));
   }
   MMPL_DEV void advance_v() {
     vslot = RING * TILE + ((vslot + TILE) & (RING * TILE - 1));
-    if (vt + 1 < T) {
+    if (__builtin_expect(vplain > 0, 1)) {
+      --vplain;
       ++vt;
-      const bool was_ragged = vrow0 + KVB > page_rows;
-      vrow0 += KVB;
-      vptr += (size_t)KVB * ldv;
-      if (vrow0 >= page_rows) {
-        vrow0 = 0;
+      vsoff += tile_bytes_v;
+    } else if (vt + 1 < T) {
+      ++vt;
+      if ((t_first + vt) % tiles_pp == 0) {
         ++vpg;
-        vptr = v_pages[vpg] + head * 128 - DMA_BIAS / 2;
+        vsrd = page_srd(v_pages[vpg], head, page_rows, ldv);
+        vsoff = 0;
+      } else {
+        vsoff += tile_bytes_v;
       }
-      if (was_ragged || vrow0 + KVB > page_rows) set_v_offsets(min(KVB - 1, page_rows - 1 - vrow0));
+      vplain = plain_run(vt);
     }
-    asm volatile("" : "+s"(vptr));
   }
+  MMPL_DEV void mfma_write_pad() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
   MMPL_DEV void rotate() {                               // end of B(j): the next B phase reads the next ring slots
     rk = (rk + TILE) & (RING * TILE - 1);
     rv = (rv + TILE) & (RING * TILE - 1);
@@ -189,6 +215,7 @@ struct Ctx {
   // ---------------------------------------------------------------- softmax streams (placement: attn_w64_sched.inc)
   // pair q of stream X: registers e, e+1 of S_X[h]; packed into word wd of P_X[ks]
   template <int MODE, int X, int Q, int EL> MMPL_DEV void sm_e() {
+    if constexpr (W64_ABL & 2) return;
     constexpr int h = Q >> 3, e = (Q & 7) * 2 + EL;
     if constexpr (MODE == 0)
       asm volatile("v_exp_f32 %0, %1" : "=v"(t[X][Q & 1][EL]) : "v"(S[X][h][e]));
@@ -198,20 +225,28 @@ struct Ctx {
   template <int MODE, int X, int Q> MMPL_DEV void sm_e0() { sm_e<MODE, X, Q, 0>(); }
   template <int MODE, int X, int Q> MMPL_DEV void sm_e1() { sm_e<MODE, X, Q, 1>(); }
   template <int MODE, int X, int Q> MMPL_DEV void sm_a0() {
+    if constexpr (W64_ABL & 2) return;
     if constexpr (Q == 0) la[X] = t[X][0][0];
     else asm volatile("v_add_f32 %0, %0, %1" : "+v"(la[X]) : "v"(t[X][Q & 1][0]));
   }
   template <int MODE, int X, int Q> MMPL_DEV void sm_a1() {
+    if constexpr (W64_ABL & 2) return;
     if constexpr (Q == 0) lb[X] = t[X][0][1];
     else asm volatile("v_add_f32 %0, %0, %1" : "+v"(lb[X]) : "v"(t[X][Q & 1][1]));
   }
   template <int MODE, int X, int Q> MMPL_DEV void sm_c() {
+    if constexpr (W64_ABL & 2) return;
     constexpr int ks = Q >> 2, wd = Q & 3;
     asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(P[X][ks][wd]) : "v"(t[X][Q & 1][0]), "v"(t[X][Q & 1][1]));
   }
   // the tile stream X is about to start: mask the rows past the end of a page's ragged last tile
   template <int X> MMPL_DEV void mask() {
-    const int valid = page_rows - crow[X];
+    if (__builtin_expect(mleft[X] > 0, 1)) {
+      --mleft[X];
+      return;
+    }
+    mleft[X] = tiles_pp - 1;
+    const int valid = page_rows - (tiles_pp - 1) * KVB;            // rows of a page's last tile
     if (valid < KVB) {
       // register r of half h holds kv row 32 h + 8 (r >> 2) + (r & 3) + 4 hi: one compare of 4 hi against a scalar per register
       // (written as asm so that the 32 compares do not all stay live in SGPR pairs at once)
@@ -224,8 +259,6 @@ struct Ctx {
         asm volatile("v_cmp_le_i32 vcc, %2, %1\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(self->S[X][h][r]) : "v"(hi4), "s"(thr), "v"(ninf) : "vcc");
       });
     }
-    crow[X] += KVB;
-    if (crow[X] >= page_rows) crow[X] = 0;
   }
   // Slow path of one tile of stream X (see the header): returns the tile's partial row sum.
   template <int X> MMPL_DEV float slow(float lt) {
@@ -267,8 +300,9 @@ struct Ctx {
     return lt;
   }
   template <int MODE, int X> MMPL_DEV void finish() {
+    if constexpr (W64_ABL & 2) return;
     float lt = la[X] + lb[X];
-    if (first[X] || __any(!(lt <= (MODE == 0 ? BOUND_FAST : BOUND_GEN)))) lt = slow<X>(lt);
+    if (__builtin_expect(first[X] || __any(!(lt <= (MODE == 0 ? BOUND_FAST : BOUND_GEN))), 0)) lt = slow<X>(lt);
     l[X] += lt;
   }
 };
@@ -341,19 +375,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   k.ldk = a.ldk; k.ldv = a.ldv; k.page_rows = a.page_rows; k.head = head; k.T = T;
   k.drow = lane >> 4; k.dchunk = lane & 15;
   k.prow = 16 * wave + k.drow;                        // LDS row of piece 4w; piece 4w + k: + 4 k
+  k.t_first = t_first; k.tiles_pp = tiles_pp;
   k.kpg = k.vpg = t_first / tiles_pp;
-  k.krow0 = k.vrow0 = (t_first % tiles_pp) * KVB;
   k.kt = k.vt = 0;
-  k.kptr = a.k_pages[k.kpg] + (size_t)k.krow0 * a.ldk + head * 128 - DMA_BIAS / 2;
-  k.vptr = a.v_pages[k.vpg] + (size_t)k.vrow0 * a.ldv + head * 128 - DMA_BIAS / 2;
+  k.kplain = k.vplain = k.plain_run(0);
+  k.tile_bytes_k = (uint32_t)KVB * a.ldk * 2u;
+  k.tile_bytes_v = (uint32_t)KVB * a.ldv * 2u;
+  k.ksrd = Ctx::page_srd(a.k_pages[k.kpg], head, a.page_rows, a.ldk);
+  k.vsrd = Ctx::page_srd(a.v_pages[k.vpg], head, a.page_rows, a.ldv);
+  k.ksoff = (uint32_t)(t_first % tiles_pp) * k.tile_bytes_k;
+  k.vsoff = (uint32_t)(t_first % tiles_pp) * k.tile_bytes_v;
   k.kslot = wave * 4096; k.vslot = RING * TILE + wave * 4096;
-  k.set_k_offsets(min(KVB - 1, a.page_rows - 1 - k.krow0));
-  k.set_v_offsets(min(KVB - 1, a.page_rows - 1 - k.vrow0));
+  // the bank swizzle is keyed on the LDS row: K chunk ^= row & 15, V chunk ^= (row & 3) << 2
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    k.dko[kk] = (uint32_t)((k.prow + 4 * kk) * a.ldk + ((k.dchunk ^ ((k.prow + 4 * kk) & 15)) << 3)) * 2u - 1024u * kk;
+    k.dvo[kk] = (uint32_t)((k.prow + 4 * kk) * a.ldv + ((k.dchunk ^ (k.drow << 2)) << 3)) * 2u - 1024u * kk;
+  }
   k.l[0] = k.l[1] = 0.f;
   k.mref[0] = k.mref[1] = 0.f;
   k.first[0] = k.first[1] = 1;
   k.gen = 0;
-  k.crow[0] = k.crow[1] = k.krow0;
+  k.mleft[0] = k.mleft[1] = tiles_pp - 1 - t_first % tiles_pp;          // tiles before each stream meets a page's last tile
   // per-lane fragment read offsets (swizzled): koff(cs) = kbase ^ 32 cs, voff(nb) = vbase ^ 64 nb
   k.kbase = l31 * 256 + 32 * ((l31 & 15) >> 1) + 16 * (hi ^ (l31 & 1));
   {

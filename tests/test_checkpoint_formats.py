@@ -103,6 +103,7 @@ def test_default_constructed_pipeline_loads_everything_from_disk(tmp_path, monke
     pipe.generator_cond.load_state_dict(checkpoints.read_mmpl_checkpoint(pt))           # Wan_fps_inference_1gpu.py:66-68
     pipe.text_encoder.tokenizer = _Tok()
     noise = philox_normal([1, 21, 16, *LAT], 23).cuda()
+    torch.manual_seed(77)                      # the stage loop draws fresh noise for the re-noised frames (torch.randn_like)
     video, lat = pipe.inference(noise, ["a cat"], return_latents=True)
     # the same tensors handed over in memory
     gen = ww.WanFPSWrapper(is_causal=True, timestep_shift=5.0, model_config=DIT, geometry=geo, device="cuda:0")
@@ -110,5 +111,6 @@ def test_default_constructed_pipeline_loads_everything_from_disk(tmp_path, monke
     enc = ww.WanTextEncoder(state_dict=t5_state_dict(T5_CONFIGS["tiny"], seed=9), cfg=T5_CONFIGS["tiny"], tokenizer=_Tok(), device="cuda:0")
     vae = ww.WanVAEWrapper(geometry=geo, device="cuda:0", state_dict=vae_state_dict(seed=3))
     pipe2 = CausalFPSInferencePipeline(args, "cuda:0", generator=gen, text_encoder=enc, vae=vae, save=None, geometry=geo)
+    torch.manual_seed(77)
     video2, lat2 = pipe2.inference(noise, ["a cat"], return_latents=True)
     assert torch.isfinite(lat.float()).all() and torch.equal(lat, lat2) and torch.equal(video, video2)

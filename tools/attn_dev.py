@@ -119,7 +119,9 @@ def bench(variants, iters=3, rounds=3, stages=("s0", "s1", "s2", "s3")):
         if name not in stages:
             continue
         Lq = nq * S
-        q = torch.randn(Lq, 3 * d, device=dev).to(BF)
+        q32 = torch.randn(Lq, 3 * d, device=dev)
+        q, qp = q32.to(BF), (q32 * CQ).to(BF)
+        del q32
         kp = (C.c_void_p * npg)(*[kc[i * S:].data_ptr() for i in range(npg)])
         vp = (C.c_void_p * npg)(*[vc[i * S:].data_ptr() for i in range(npg)])
         outs, best = {}, {v: 0.0 for v in variants}
@@ -127,7 +129,7 @@ def bench(variants, iters=3, rounds=3, stages=("s0", "s1", "s2", "s3")):
         for _ in range(rounds):
             for var in variants:
                 o = torch.zeros(Lq, d, device=dev, dtype=BF)
-                ms = timeit(lambda: run(var, q, 3 * d, o, d, kp, vp, npg, S, Lq, H), iters)
+                ms = timeit(lambda: run(var, qp if var == 4 else q, 3 * d, o, d, kp, vp, npg, S, Lq, H), iters)
                 outs[var] = o
                 tf = 4.0 * Lq * npg * S * d / ms / 1e9
                 best[var] = max(best[var], tf)

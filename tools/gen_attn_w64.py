@@ -148,6 +148,10 @@ def emit():
                 lines.append(f"  if constexpr (QK) k.template mfma_qk<{x}, {g}>();")
             else:
                 lines.append(f"  if constexpr (PV) k.template mfma_pv<{x}, {g - 16}>();")
+            if g == 16:
+                # a phase without the PV MFMAs (the first tile): nothing covers the 19 wait states between the last QK MFMA's
+                # write of S and the first VALU read of it (a software hazard, not interlocked)
+                lines.append("  if constexpr (QK && !PV) k.mfma_write_pad();")
             sm = interleave(placed[base + g])
             fx = list(fixed[g])
             body = []
