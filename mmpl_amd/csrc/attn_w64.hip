@@ -21,12 +21,19 @@
 // accumulator is finished >= 2 MFMAs before the VALU touches it and each P >= 2 gaps before its MFMA.
 //
 // Softmax without a row max on the common path.  Q is prescaled, so S is in log2 units and p = exp2(S - m_ref) against a per-row
-// reference m_ref.  FAST mode: m_ref = 0 for every row of the wave (p = exp2(S): one v_exp, one add and half a cvt_pk per
-// score); entered when the first tile's row maxima are all within +-2^6.  GENERAL mode: p = exp2(S - m_ref) (one more VALU
-// per score).  Either way a tile is accepted when every lane's partial row sum is <= a bound (2^80 / 2^30); otherwise it is
-// redone on a slow path (exact row max, m_ref = max(m_ref, max), O and l rescaled through v_accvgpr moves, p recomputed) and
-// the wave continues in GENERAL mode.  So p never overflows, l >= 2^-64 after the first tile, and the result is the exact
-// softmax up to rounding for any input (tests: spiked scores far beyond both bounds).
+// reference m_ref.  FAST pass: m_ref = 0 for every row (p = exp2(S): one v_exp, one add and half a cvt_pk per score, and NOTHING
+// per tile that could branch).  Every p is >= 0, so the row sums only grow: one look at them after the last tile tells whether
+// any exponential overflowed or all of them underflowed (2^-40 <= l <= 2^100 is required, NaN fails).  If any row of the block
+// fails, the whole block is redone by the GENERAL pass: p = exp2(S - m_ref) (one more VALU per score), a tile is accepted when
+// every lane's partial row sum is <= 2^30, otherwise it is redone on a slow path (exact row max, m_ref = max(m_ref, max), O and
+// l rescaled through v_accvgpr moves, p recomputed).  So the result is the exact softmax up to rounding for any input (tests:
+// spiked scores far beyond both bounds); inputs that a FAST pass cannot hold cost that block two passes.
+//
+// Nothing in the steady loop branches except its back edge.  Everything that happens once per page -- the K / V cursors
+// switching buffer descriptors, the ragged last tile's mask, a cursor parking on the block's last tile -- is decided between
+// RUNS of identical iterations (Ctx::plan): a run ends where the next such event is due.  The mask is the C operand of each
+// score tile's first MFMA: a register tile that is all zero except during a page's ragged last tile (-inf on the rows past
+// the page's end, whose K and V rows the LDS-DMA's range check zero-filled).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -38,10 +45,9 @@
 namespace {
 
 constexpr int QB = 256, KVB = 64, TILE = KVB * 256, RING = 4;         // K ring [0, 64 KiB), V ring [64 KiB, 128 KiB)
-constexpr int W64_SMEM = 2 * RING * TILE;
-constexpr float BOUND_FAST = 1.2089258e24f;                            // 2^80
-constexpr float BOUND_GEN = 1073741824.f;                              // 2^30
-constexpr float FIRST_RANGE = 64.f;
+constexpr int W64_SMEM = 2 * RING * TILE + 64;     // + the block's redo flag
+constexpr float BOUND_GEN = 1073741824.f;                              // 2^30: a GENERAL tile's partial row sums
+constexpr float FAST_L_MIN = 9.094947e-13f, FAST_L_MAX = 1.2676506e30f;       // 2^-40, 2^100: a FAST pass's final row sums
 
 template <int I> using ic = std::integral_constant<int, I>;
 template <class F, int... I> MMPL_DEV void sfor_(F&& f, std::integer_sequence<int, I...>) { (f(ic<I>{}), ...); }
@@ -56,7 +62,8 @@ template <int N, class F> MMPL_DEV void sfor(F&& f) { sfor_(f, std::make_integer
 constexpr int AO = 0, AQ = 128, AV = 192;      // accumulator-file map
 
 // Timing ablations for tools/w64_sweep.sh (results are garbage): -DW64_ABL=<bits>  1 no LDS-DMA in the loop, 2 no softmax,
-// 4 no fragment reads, 8 no barrier / waits.  0 in every shipped build.
+// 4 no fragment reads, 8 no barrier / waits, 16 leave per-wave loop cycle counts in o (tools/attn_dev.py cycles), 32 / 64 / 128
+// no exp / row-sum adds / bf16 packs.  0 in every shipped build.
 #ifndef W64_ABL
 #define W64_ABL 0
 #endif
@@ -66,6 +73,7 @@ constexpr int AO = 0, AQ = 128, AV = 192;      // accumulator-file map
 struct Ctx {
   // ---- vector state
   f32x16 S[2][2];        // [query block][kv half]
+  f32x16 M[2];           // [kv half] C operand of a score tile's first MFMA: 0, or -inf on the rows past a page's end
   u32x4 P[2][4];         // [query block][16-row kv step]: 8 bf16 = B operand of O^T += V^T.P^T
   bf16x8 kf[16];         // K fragments of one tile: i = 2*chunk + half
   float l[2], mref[2];   // running row sum (this lane's 32 kv columns of every tile) and reference (log2 units)
@@ -79,21 +87,20 @@ struct Ctx {
   int ldk, ldv, page_rows, head, T;
   u32x4 ksrd, vsrd;                            // buffer descriptors of the cursors' pages (this head's 256-byte column)
   uint32_t ksoff, vsoff, tile_bytes_k, tile_bytes_v;   // byte offset of the cursor tile's first row within its page
-  int kpg, kt, vpg, vt;                        // cursors: page, tile index within the block
-  int kplain, vplain;                          // advances left before the cursor leaves its page or meets the block's end
-  int t_first, tiles_pp;
+  uint32_t kstep, vstep;                       // what an iteration adds to ksoff / vsoff: the tile's bytes, 0 once parked
+  int t_first, tiles_pp, masked;               // masked: M is not all zero
   uint32_t kslot, vslot;                       // LDS address of this wave's piece 0 in the slot the cursor tile goes to
   uint32_t rk, rv;                             // ring offsets of the tiles the next B phase reads (K(j+1), V(j))
-  int mleft[2];                                // tiles before the next ragged one (a page's last) of each softmax stream
-  int first[2];                                // stream has not finished its first tile yet
-  int gen;                                     // wave is in GENERAL mode
+  int first[2];                                // GENERAL pass: stream has not finished its first tile yet
   int prow, drow, dchunk;
+  uint32_t wave_slot;                          // this wave's first piece within a ring slot
+  unsigned long long ticks;                    // W64_ABL & 16: shader cycles of the pass's steady loop
 
   // ---------------------------------------------------------------- MFMAs
   template <int X, int G> MMPL_DEV void mfma_qk() {      // S_X[h] (+)= K frag G . Q_X[chunk]
     constexpr int c = G >> 1, h = G & 1, qa = AQ + 32 * X + 4 * c;
     if constexpr (c == 0)
-      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(S[X][h]) : "v"(kf[G]), "i"(qa), "i"(qa + 3));
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %4" : "=&v"(S[X][h]) : "v"(kf[G]), "i"(qa), "i"(qa + 3), "v"(M[h]));
     else
       asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(S[X][h]) : "v"(kf[G]), "i"(qa), "i"(qa + 3));
   }
@@ -163,48 +170,69 @@ struct Ctx {
     r[3] = 0x00020000u;
     return r;
   }
-  // Cursors stop on the block's last tile (it is simply re-fetched), so every event issues exactly 8 pieces and the counted
-  // waits never change.  The common advance -- next tile exists and lies in the same page -- is three SALU instructions
-  // behind ONE not-taken branch (a countdown); page switches and the block's end take the out-of-line path.
-  MMPL_DEV int plain_run(int t) const {                // advances from tile t (block-relative) that stay in its page and in the block
-    const int pos = (t_first + t) % tiles_pp;
-    return __builtin_amdgcn_readfirstlane(max(min(tiles_pp - 1 - pos, T - 1 - t), 0));
+  // Cursor arithmetic.  Inside a run an iteration only adds kstep / vstep to the scalar offsets (no branch); plan(j), called
+  // between runs, places both cursors for iteration j from scratch (K at tile j + 4, V at j + 2, each parked on the block's last
+  // tile once it gets there -- that tile is simply re-fetched, so every event issues exactly 8 pieces and the counted waits
+  // never change), sets or clears the mask tile for tile j, and returns how many iterations may run before the next event.
+  MMPL_DEV void seek_k(int t, int& pos) {
+    const int at = t_first + t, pg = at / tiles_pp;
+    pos = at - pg * tiles_pp;
+    ksrd = page_srd(k_pages[pg], head, page_rows, ldk);
+    ksoff = (uint32_t)pos * tile_bytes_k;
+  }
+  MMPL_DEV void seek_v(int t, int& pos) {
+    const int at = t_first + t, pg = at / tiles_pp;
+    pos = at - pg * tiles_pp;
+    vsrd = page_srd(v_pages[pg], head, page_rows, ldv);
+    vsoff = (uint32_t)pos * tile_bytes_v;
+  }
+  MMPL_DEV void set_mask(int valid) {
+    // register r of half h holds kv row 32 h + 8 (r >> 2) + (r & 3) + 4 hi: one compare of 4 hi against a scalar per register
+    // (written as asm so that the 32 compares do not all stay live in SGPR pairs at once)
+    const int hi4 = 4 * hi;
+    const float ninf = -INFINITY, zero = 0.f;
+    Ctx* self = this;
+    sfor<32>([self, hi4, ninf, zero, valid](auto ii) {
+      constexpr int i = decltype(ii)::value, h = i >> 4, r = i & 15;
+      const int thr = valid - (32 * h + 8 * (r >> 2) + (r & 3));          // masked iff 4 hi >= thr
+      asm volatile("v_cmp_le_i32 vcc, %2, %1\n\tv_cndmask_b32 %0, %4, %3, vcc" : "=v"(self->M[h][r]) : "v"(hi4), "s"(thr), "v"(ninf), "v"(zero) : "vcc");
+    });
+    masked = 1;
+  }
+  MMPL_DEV void clear_mask() {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) M[h][r] = 0.f;
+    masked = 0;
+  }
+  MMPL_DEV int plan(int j) {
+    int n = T - j, pos;
+    const int tk = min(j + 4, T - 1), tv = min(j + 2, T - 1);
+    seek_k(tk, pos);
+    kstep = 0;
+    if (tk < T - 1) { kstep = tile_bytes_k; n = min(n, min(tiles_pp - pos, T - tk)); }
+    seek_v(tv, pos);
+    vstep = 0;
+    if (tv < T - 1) { vstep = tile_bytes_v; n = min(n, min(tiles_pp - pos, T - tv)); }
+    const int valid = page_rows - (tiles_pp - 1) * KVB;                  // rows of a page's last tile
+    const int pos_j = (t_first + j) % tiles_pp;
+    if (valid < KVB && pos_j == tiles_pp - 1) {
+      set_mask(valid);
+      n = 1;
+    } else {
+      if (masked) clear_mask();
+      if (valid < KVB) n = min(n, tiles_pp - 1 - pos_j);
+    }
+    return __builtin_amdgcn_readfirstlane(n);
   }
   MMPL_DEV void advance_k() {
     kslot = (kslot + TILE) & (RING * TILE - 1);
-    if (__builtin_expect(kplain > 0, 1)) {
-      --kplain;
-      ++kt;
-      ksoff += tile_bytes_k;
-    } else if (kt + 1 < T) {
-      ++kt;
-      if ((t_first + kt) % tiles_pp == 0) {
-        ++kpg;
-        ksrd = page_srd(k_pages[kpg], head, page_rows, ldk);
-        ksoff = 0;
-      } else {
-        ksoff += tile_bytes_k;
-      }
-      kplain = plain_run(kt);
-    }
+    ksoff += kstep;
   }
   MMPL_DEV void advance_v() {
     vslot = RING * TILE + ((vslot + TILE) & (RING * TILE - 1));
-    if (__builtin_expect(vplain > 0, 1)) {
-      --vplain;
-      ++vt;
-      vsoff += tile_bytes_v;
-    } else if (vt + 1 < T) {
-      ++vt;
-      if ((t_first + vt) % tiles_pp == 0) {
-        ++vpg;
-        vsrd = page_srd(v_pages[vpg], head, page_rows, ldv);
-        vsoff = 0;
-      } else {
-        vsoff += tile_bytes_v;
-      }
-      vplain = plain_run(vt);
-    }
+    vsoff += vstep;
   }
   MMPL_DEV void mfma_write_pad() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
   MMPL_DEV void rotate() {                               // end of B(j): the next B phase reads the next ring slots
@@ -215,7 +243,7 @@ struct Ctx {
   // ---------------------------------------------------------------- softmax streams (placement: attn_w64_sched.inc)
   // pair q of stream X: registers e, e+1 of S_X[h]; packed into word wd of P_X[ks]
   template <int MODE, int X, int Q, int EL> MMPL_DEV void sm_e() {
-    if constexpr (W64_ABL & 2) return;
+    if constexpr (W64_ABL & (2 | 32)) return;
     constexpr int h = Q >> 3, e = (Q & 7) * 2 + EL;
     if constexpr (MODE == 0)
       asm volatile("v_exp_f32 %0, %1" : "=v"(t[X][Q & 1][EL]) : "v"(S[X][h][e]));
@@ -225,42 +253,21 @@ struct Ctx {
   template <int MODE, int X, int Q> MMPL_DEV void sm_e0() { sm_e<MODE, X, Q, 0>(); }
   template <int MODE, int X, int Q> MMPL_DEV void sm_e1() { sm_e<MODE, X, Q, 1>(); }
   template <int MODE, int X, int Q> MMPL_DEV void sm_a0() {
-    if constexpr (W64_ABL & 2) return;
-    if constexpr (Q == 0) la[X] = t[X][0][0];
+    if constexpr (W64_ABL & (2 | 64)) return;
+    if constexpr (Q == 0 && MODE == 1) la[X] = t[X][0][0];
     else asm volatile("v_add_f32 %0, %0, %1" : "+v"(la[X]) : "v"(t[X][Q & 1][0]));
   }
   template <int MODE, int X, int Q> MMPL_DEV void sm_a1() {
-    if constexpr (W64_ABL & 2) return;
-    if constexpr (Q == 0) lb[X] = t[X][0][1];
+    if constexpr (W64_ABL & (2 | 64)) return;
+    if constexpr (Q == 0 && MODE == 1) lb[X] = t[X][0][1];
     else asm volatile("v_add_f32 %0, %0, %1" : "+v"(lb[X]) : "v"(t[X][Q & 1][1]));
   }
   template <int MODE, int X, int Q> MMPL_DEV void sm_c() {
-    if constexpr (W64_ABL & 2) return;
+    if constexpr (W64_ABL & (2 | 128)) return;
     constexpr int ks = Q >> 2, wd = Q & 3;
     asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(P[X][ks][wd]) : "v"(t[X][Q & 1][0]), "v"(t[X][Q & 1][1]));
   }
-  // the tile stream X is about to start: mask the rows past the end of a page's ragged last tile
-  template <int X> MMPL_DEV void mask() {
-    if (__builtin_expect(mleft[X] > 0, 1)) {
-      --mleft[X];
-      return;
-    }
-    mleft[X] = tiles_pp - 1;
-    const int valid = page_rows - (tiles_pp - 1) * KVB;            // rows of a page's last tile
-    if (valid < KVB) {
-      // register r of half h holds kv row 32 h + 8 (r >> 2) + (r & 3) + 4 hi: one compare of 4 hi against a scalar per register
-      // (written as asm so that the 32 compares do not all stay live in SGPR pairs at once)
-      const int hi4 = 4 * hi;
-      const float ninf = -INFINITY;
-      Ctx* self = this;
-      sfor<32>([self, hi4, ninf, valid](auto ii) {
-        constexpr int i = decltype(ii)::value, h = i >> 4, r = i & 15;
-        const int thr = valid - (32 * h + 8 * (r >> 2) + (r & 3));          // masked iff 4 hi >= thr
-        asm volatile("v_cmp_le_i32 vcc, %2, %1\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(self->S[X][h][r]) : "v"(hi4), "s"(thr), "v"(ninf) : "vcc");
-      });
-    }
-  }
-  // Slow path of one tile of stream X (see the header): returns the tile's partial row sum.
+  // GENERAL pass, slow path of one tile of stream X (see the header): returns the tile's partial row sum.
   template <int X> MMPL_DEV float slow(float lt) {
     float mx = S[X][0][0];
 #pragma unroll
@@ -270,8 +277,6 @@ struct Ctx {
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     if (first[X]) {
       first[X] = 0;
-      // first tile: stay on reference 0 if every row's maximum is moderate (the optimistic tile is then valid as computed)
-      if (!gen && !__any(!(fabsf(mx) <= FIRST_RANGE))) return lt;
       mref[X] = mx;                                   // O = l = 0: nothing to rescale
     } else {
       const float m_new = fmaxf(mref[X], mx);
@@ -286,7 +291,6 @@ struct Ctx {
         asm volatile("v_accvgpr_write_b32 a[%c0], %1" ::"i"(AO + 64 * X + i), "v"(v));
       });
     }
-    gen = 1;
     lt = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -300,14 +304,72 @@ struct Ctx {
     return lt;
   }
   template <int MODE, int X> MMPL_DEV void finish() {
-    if constexpr (W64_ABL & 2) return;
+    if constexpr (MODE == 0 || (W64_ABL & (2 | 4 | 32 | 64 | 128))) return;     // FAST: la / lb run on; timing ablations: no slow path
     float lt = la[X] + lb[X];
-    if (__builtin_expect(first[X] || __any(!(lt <= (MODE == 0 ? BOUND_FAST : BOUND_GEN))), 0)) lt = slow<X>(lt);
+    if (__builtin_expect(first[X] || __any(!(lt <= BOUND_GEN)), 0)) lt = slow<X>(lt);
     l[X] += lt;
   }
 };
 
 #include "attn_w64_sched.inc"
+
+// One pass over the block's KV tiles in softmax mode MODE (0 FAST, 1 GENERAL): O in a[0:127], row sums in la / lb (FAST) or l
+// (GENERAL), references in mref.
+template <int MODE> MMPL_DEV void w64_pass(Ctx& k) {
+  const int T = k.T;
+  sfor<128>([](auto ii) { asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(AO + decltype(ii)::value)); });
+  k.l[0] = k.l[1] = 0.f;
+  k.la[0] = k.la[1] = k.lb[0] = k.lb[1] = 0.f;
+  k.mref[0] = k.mref[1] = 0.f;
+  k.first[0] = k.first[1] = 1;
+  k.clear_mask();
+  k.kslot = k.wave_slot; k.vslot = RING * TILE + k.wave_slot;
+  k.rk = TILE; k.rv = 0;
+  k.kstep = k.vstep = 0;
+
+  // ---- prologue: DMA events -4 .. -1 (event e = { K(e+4), V(e+2) }), then the K(0) fragments
+  int pos;
+  k.seek_k(0, pos);
+  sfor<4>([&k](auto kk) { k.template dma_k<decltype(kk)::value>(); });
+  k.advance_k();
+  k.seek_k(min(1, T - 1), pos);
+  sfor<4>([&k](auto kk) { k.template dma_k<decltype(kk)::value>(); });
+  k.advance_k();
+#pragma unroll 1
+  for (int e = 0; e < 2; ++e) {
+    k.seek_k(min(e + 2, T - 1), pos);
+    k.seek_v(min(e, T - 1), pos);
+    sfor<4>([&k](auto kk) { k.template dma_k<decltype(kk)::value>(); });
+    sfor<4>([&k](auto kk) { k.template dma_v<decltype(kk)::value>(); });
+    k.advance_k();
+    k.advance_v();
+  }
+  asm volatile("s_waitcnt vmcnt(20)\n\ts_barrier" ::: "memory");
+  k.kaddr = k.kbase;
+  sfor<16>([&k](auto gi) { k.template lds_k<decltype(gi)::value>(); });
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  k.plan(0);
+  w64_phase_a<MODE, true, false, true, false>(k);
+  w64_phase_b<MODE, true, false, true, false>(k);
+  [[maybe_unused]] unsigned long long tick0 = 0;
+  if constexpr (W64_ABL & 16) tick0 = __builtin_readcyclecounter();
+  // runs of identical, branch-free iterations; whatever happens once per page is decided in between (Ctx::plan)
+#pragma unroll 1
+  for (int j = 1; j < T;) {
+    const int n = k.plan(j);
+    j += n;
+#pragma unroll 1
+    for (int i = 0; i < n; ++i) {
+      w64_phase_a<MODE, true, true, true, true>(k);
+      w64_phase_b<MODE, true, true, true, true>(k);
+    }
+  }
+  if constexpr (W64_ABL & 16) k.ticks = __builtin_readcyclecounter() - tick0;
+  w64_phase_a<MODE, false, true, false, true>(k);
+  w64_phase_b<MODE, false, true, false, true>(k);
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+}
 
 template <bool SPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_w64_kernel(AttnArgs a, int local_base, int sp) {
@@ -336,7 +398,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   // the accumulator file is ours: this statement makes the kernel descriptor allocate all 256 entries
   asm volatile("s_nop 0" ::: ALL_AGPRS);
-  sfor<128>([](auto ii) { asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(AO + decltype(ii)::value)); });
 
   // ---- Q fragments -> a[128:191], prescaled: lane (l31, hi) holds Q[row][16c + 8*hi .. +8] * scale * log2(e).  The DiT forward
   // folds that factor into q where q is produced (qknorm_kernel, before the rounding to bf16: q_prescaled); a raw q is scaled
@@ -376,75 +437,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   k.drow = lane >> 4; k.dchunk = lane & 15;
   k.prow = 16 * wave + k.drow;                        // LDS row of piece 4w; piece 4w + k: + 4 k
   k.t_first = t_first; k.tiles_pp = tiles_pp;
-  k.kpg = k.vpg = t_first / tiles_pp;
-  k.kt = k.vt = 0;
-  k.kplain = k.vplain = k.plain_run(0);
   k.tile_bytes_k = (uint32_t)KVB * a.ldk * 2u;
   k.tile_bytes_v = (uint32_t)KVB * a.ldv * 2u;
-  k.ksrd = Ctx::page_srd(a.k_pages[k.kpg], head, a.page_rows, a.ldk);
-  k.vsrd = Ctx::page_srd(a.v_pages[k.vpg], head, a.page_rows, a.ldv);
-  k.ksoff = (uint32_t)(t_first % tiles_pp) * k.tile_bytes_k;
-  k.vsoff = (uint32_t)(t_first % tiles_pp) * k.tile_bytes_v;
-  k.kslot = wave * 4096; k.vslot = RING * TILE + wave * 4096;
+  k.wave_slot = wave * 4096;
   // the bank swizzle is keyed on the LDS row: K chunk ^= row & 15, V chunk ^= (row & 3) << 2
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
     k.dko[kk] = (uint32_t)((k.prow + 4 * kk) * a.ldk + ((k.dchunk ^ ((k.prow + 4 * kk) & 15)) << 3)) * 2u - 1024u * kk;
     k.dvo[kk] = (uint32_t)((k.prow + 4 * kk) * a.ldv + ((k.dchunk ^ (k.drow << 2)) << 3)) * 2u - 1024u * kk;
   }
-  k.l[0] = k.l[1] = 0.f;
-  k.mref[0] = k.mref[1] = 0.f;
-  k.first[0] = k.first[1] = 1;
-  k.gen = 0;
-  k.mleft[0] = k.mleft[1] = tiles_pp - 1 - t_first % tiles_pp;          // tiles before each stream meets a page's last tile
   // per-lane fragment read offsets (swizzled): koff(cs) = kbase ^ 32 cs, voff(nb) = vbase ^ 64 nb
   k.kbase = l31 * 256 + 32 * ((l31 & 15) >> 1) + 16 * (hi ^ (l31 & 1));
   {
     const int i16 = lane & 15, g16 = (lane >> 4) & 1;
     k.vbase = RING * TILE + (4 * hi + (i16 >> 2)) * 256 + 64 * (i16 >> 2) + 32 * g16 + 8 * (i16 & 3);
   }
-  k.rk = TILE; k.rv = 0;
 
-  // ---- prologue: DMA events -4 .. -1 (event e = { K(e+4), V(e+2) }), then the K(0) fragments
-  sfor<4>([&k](auto kk) { k.template dma_k<decltype(kk)::value>(); });
-  k.advance_k();
-  sfor<4>([&k](auto kk) { k.template dma_k<decltype(kk)::value>(); });
-  k.advance_k();
-#pragma unroll 1
-  for (int e = 0; e < 2; ++e) {
-    sfor<4>([&k](auto kk) { k.template dma_k<decltype(kk)::value>(); });
-    sfor<4>([&k](auto kk) { k.template dma_v<decltype(kk)::value>(); });
-    k.advance_k();
-    k.advance_v();
+  // ---- the FAST pass; if any row of the block cannot be held by it (see the header), the GENERAL pass from scratch
+  extern __shared__ __attribute__((aligned(16))) char w64_smem[];
+  volatile int* redo = reinterpret_cast<volatile int*>(w64_smem + 2 * RING * TILE);
+  if (tid == 0) *redo = 0;                             // ordered before the vote by the passes' barriers
+  w64_pass<0>(k);
+  {
+    bool bad = false;
+#pragma unroll
+    for (int X = 0; X < 2; ++X) {
+      k.l[X] = k.la[X] + k.lb[X];
+      const float l_tot = k.l[X] + __shfl_xor(k.l[X], 32, 64);
+      bad |= !(l_tot >= FAST_L_MIN && l_tot <= FAST_L_MAX);
+    }
+    if constexpr (W64_ABL != 0) bad = false;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // the parked cursors' last re-fetches
+    if (__any(bad) && lane == 0) *redo = 1;
+    __syncthreads();
+    if (*redo) w64_pass<1>(k);
   }
-  asm volatile("s_waitcnt vmcnt(20)\n\ts_barrier" ::: "memory");
-  k.kaddr = k.kbase;
-  sfor<16>([&k](auto gi) { k.template lds_k<decltype(gi)::value>(); });
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-
-  w64_phase_a<0, true, false, true, false>(k);
-  w64_phase_b<0, true, false, true, false>(k);
-  // two plain loops rather than one loop with a mode branch inside (which hipcc cannot allocate without spilling into the
-  // accumulator file): the wave leaves FAST mode at most once
-  int j = 1;
-#pragma unroll 1
-  for (; j < T && !k.gen; ++j) {
-    w64_phase_a<0, true, true, true, true>(k);
-    w64_phase_b<0, true, true, true, true>(k);
-  }
-#pragma unroll 1
-  for (; j < T; ++j) {
-    w64_phase_a<1, true, true, true, true>(k);
-    w64_phase_b<1, true, true, true, true>(k);
-  }
-  if (!k.gen) {
-    w64_phase_a<0, false, true, false, true>(k);
-    w64_phase_b<0, false, true, false, true>(k);
-  } else {
-    w64_phase_a<1, false, true, false, true>(k);
-    w64_phase_b<1, false, true, false, true>(k);
-  }
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
   // ---- epilogue: lane (q = l31, hi) holds O_X[q][32*nb + 8*g + 4*hi + {0..3}] in a[64 X + 16 nb + 4 g ..+3]
 #pragma unroll
@@ -471,7 +498,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     } else {
       const float inv = 1.0f / l_tot;
       const int q_out = qb * QB + rr;
-      if (q_out < a.Lq) {
+      if constexpr (W64_ABL & 16) {
+        // timing build (dev): instead of O, each wave leaves { shader cycles of its steady loops, tiles in them }
+        if (X == 0 && lane == 0) {
+          float* tp = reinterpret_cast<float*>(a.o) + (blockIdx.x * 4 + wave) * 2;
+          tp[0] = (float)k.ticks;
+          tp[1] = (float)(T - 1);
+        }
+      } else if (q_out < a.Lq) {
         bf16_t* op = a.o + (size_t)q_out * a.ldo + head * 128 + 4 * hi;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)

@@ -13,6 +13,7 @@ def audit(workdir, src=SRC, own_agprs=True):
     For every source: m0 (written by the hand-issued LDS-DMA statements without a clobber) must not appear in compiler code."""
     stem = os.path.splitext(os.path.basename(src))[0]
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-c", src, "-o", stem + ".o", "-save-temps"]
+    cmd += os.environ.get("MMPL_EXTRA_HIPCC_FLAGS", "").split()
     r = subprocess.run(cmd, cwd=workdir, capture_output=True, text=True)
     if r.returncode:
         return [f"hipcc failed: {r.stderr[-2000:]}"], {}

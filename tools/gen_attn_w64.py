@@ -34,7 +34,6 @@ A_FIXED[3].append(("!QK", "k.wait_lgkm0();", 1))
 for i in range(4):
     A_FIXED[4 + i].append(("QK", f"k.template dma_k<{i}>();", BUDGET - 1))
     A_FIXED[8 + i].append(("QK", f"k.template dma_v<{i}>();", BUDGET - 1))
-A_FIXED[17].append(("S0", "k.template mask<0>();", 0.5))
 A_FIXED[19].append(("QK", "k.advance_k();", 2))
 A_FIXED[21].append(("QK", "k.advance_v();", 2))
 B_FIXED[0].append(("QK", "k.addr_k();", 1))
@@ -139,8 +138,6 @@ def emit():
         fixed = A_FIXED if ph == "A" else B_FIXED
         base = 0 if ph == "A" else 32
         lines.append(f"template <int MODE, bool QK, bool PV, bool S0, bool S1> MMPL_DEV void w64_phase_{ph.lower()}(Ctx& k) {{")
-        if ph == "A":
-            lines.append("  if constexpr (S1) k.template mask<1>();")
         for g in range(32):
             load = BUDGET - cap[base + g] + sum((W_EXP if o[1][0] == "e" else W_VALU) for o in placed[base + g])
             lines.append(f"  // ---- gap {g}: {load:.1f} slots")

@@ -9,7 +9,11 @@ for abl in $2; do
   echo "== W64_ABL=$abl" >> $out
   touch mmpl_amd/csrc/attn_w64.hip
   MMPL_EXTRA_HIPCC_FLAGS="-DW64_ABL=$abl" python -m mmpl_amd.build > /dev/null 2>&1
-  timeout 200 python tools/attn_dev.py bench 4 stages=s1,s3 2>&1 | grep attn >> $out
+  if [ $((abl & 16)) -ne 0 ]; then
+    timeout 200 python tools/attn_dev.py cycles 2>&1 | grep cycles >> $out
+  else
+    timeout 200 python tools/attn_dev.py bench 4 stages=s1,s3 2>&1 | grep attn >> $out
+  fi
 done
 touch mmpl_amd/csrc/attn_w64.hip; python -m mmpl_amd.build > /dev/null 2>&1
 cat $out
