@@ -1,4 +1,5 @@
-"""One attention launch population for rocprofv3 --pmc (dev tool): python3 tools/attn_one.py [stage] [iters]"""
+"""One attention launch population for rocprofv3 --pmc (dev tool): python3 tools/attn_one.py [stage] [iters]
+Runs the op the DiT forward runs: the w64 kernel on a producer-prescaled q, with the split-KV workspace (variant 4)."""
 import ctypes as C
 import math
 import os
@@ -19,13 +20,14 @@ H, S, d = 40, 3600, 5120
 kc = torch.randn(npg * S, d, device=dev).to(BF)
 vc = torch.randn(npg * S, d, device=dev).to(BF)
 Lq = nq * S
-q = torch.randn(Lq, 3 * d, device=dev).to(BF)
+q = (torch.randn(Lq, 3 * d, device=dev) * (1.4426950408889634 / math.sqrt(128))).to(BF)
 o = torch.empty(Lq, d, device=dev, dtype=BF)
+ws = torch.empty(lib.mmpl_attn_workspace_bytes(), dtype=torch.uint8, device=dev)
 kp = (C.c_void_p * npg)(*[kc[i * S:].data_ptr() for i in range(npg)])
 vp = (C.c_void_p * npg)(*[vc[i * S:].data_ptr() for i in range(npg)])
 
-
 for _ in range(iters):
-    _lib.check(lib.mmpl_attn_fwd(_lib.ptr(q), 3 * d, _lib.ptr(o), d, kp, vp, d, d, npg, S, Lq, H, 1 / math.sqrt(128), _lib.stream_ptr()))
+    _lib.check(lib.mmpl_attn_fwd_variant(_lib.ptr(q), 3 * d, _lib.ptr(o), d, kp, vp, d, d, npg, S, Lq, H, 1 / math.sqrt(128),
+                                         _lib.ptr(ws), ws.numel(), 4, 0, _lib.stream_ptr()))
 torch.cuda.synchronize()
 print("done", stage, float(o.float().abs().mean()))

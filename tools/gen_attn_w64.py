@@ -22,8 +22,11 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), "mmpl_amd", "csrc", "attn_w64_sched.inc")
 
-W_EXP, W_VALU = 1.5, 1.0          # issue-slot weights
-BUDGET = 5.5                      # slots per gap besides the MFMA
+# Issue-slot weights and slots per gap besides the MFMA.  Measured with the timing build (tools/w64_gen_sweep.sh, shader cycles per
+# KV tile of the steady loop, 14B/720p stage 3): BUDGET 5.5 -> 2480, 5.0 -> 2424, 6.0 -> 2545, 7.0 -> 2568 (floor: 64 MFMAs = 2114);
+# 4.5 does not fit stream 1 into phase A.
+W_EXP, W_VALU = float(os.environ.get("W64_WEXP", 1.5)), 1.0
+BUDGET = float(os.environ.get("W64_BUDGET", 5.0))
 
 # ---- fixed fillers: (flag, statement, slots)
 A_FIXED = {g: [] for g in range(32)}

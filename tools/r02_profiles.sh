@@ -1,0 +1,29 @@
+#!/bin/bash
+# Collects the judged profiles of a build on the GPU box into gpurun_out/prof_<tag>/ (copy the summaries into profiles/):
+#   bash tools/r02_profiles.sh <tag> [stats] [hbm] [busy]
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+tag=$1; shift
+what="${*:-stats hbm busy}"
+out=gpurun_out/prof_$tag; mkdir -p $out
+for w in $what; do
+  case $w in
+  stats)
+    timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o b -- python3 bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae > $out/bench_under_rocprof.json 2> $out/stats.err
+    ;;
+  hbm)
+    for st in s0 s1 s2 s3; do
+      for ctr in FETCH_SIZE WRITE_SIZE; do
+        timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc $ctr -d $out/hbm_${st}_$ctr -o p -- python3 tools/attn_one.py $st 2 > $out/hbm_${st}_$ctr.log 2>&1
+      done
+    done
+    ;;
+  busy)
+    timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $out/busy -o p -- python3 bench.py --steps 4 --warmup 0 --no-cpu-baseline --no-vae --no-profile > $out/busy_bench.json 2> $out/busy.err
+    ;;
+  esac
+done
+python3 tools/r02_profiles_post.py $out $tag
+# the raw traces are large: keep the summaries only
+find $out -name "*kernel_trace.csv" -size +8M -delete
+find $out -name "*counter_collection.csv" -size +8M -delete
+ls -la $out
