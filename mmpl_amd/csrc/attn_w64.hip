@@ -12,7 +12,7 @@
 //     S_A, S_B (2 x 32 fp32), P_A, P_B (2 x 16 packed bf16 pairs), the 16 K fragments of one tile (64), softmax state.
 //
 // Schedule.  The two query blocks run HALF A TILE APART; per KV tile j two phases of 32 MFMAs, one barrier per tile:
-//     A(j): S_A(j) = K(j).Q_A [16 MFMAs]  then  O_A += V(j-1).P_A(j-1) [16]     + LDS-DMA of K(j+4) / V(j+2), 8 pieces per wave
+//     A(j): S_A(j) = K(j).Q_A [16 MFMAs]  then  O_A += V(j-1).P_A(j-1) [16]     + LDS-DMA of K(j+4) / V(j+3), 8 pieces per wave
 //     B(j): S_B(j) = K(j).Q_B [16]        then  O_B += V(j-1).P_B(j-1) [16]     + fragment reads of K(j+1) and V(j), each right
 //                                                                                  behind the last MFMA that used its register
 // Everything that is not an MFMA is placed by tools/gen_attn_w64.py (attn_w64_sched.inc) into the gaps between them, <= ~5
@@ -132,11 +132,12 @@ struct Ctx {
   }
   template <int N> MMPL_DEV void wait_lgkm() { if constexpr (W64_ABL & 8) return; asm volatile("s_waitcnt lgkmcnt(%c0)" ::"i"(N) : "memory"); }
   MMPL_DEV void wait_lgkm0() { if constexpr (W64_ABL & 8) return; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-  // K(j+1) and V(j) (DMA events j-3 and j-2) have landed when at most the 8 pieces of event j-1 are outstanding; all of this
-  // wave's fragment reads of the slots event j is about to overwrite are complete (lgkmcnt 0)
-  MMPL_DEV void barrier() { if constexpr (W64_ABL & 8) return; asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+  // K(j+1) and V(j) (DMA event j-3) have landed when at most the 16 pieces of events j-1 and j-2 are outstanding -- two whole
+  // tile times of latency cover (with one, vmcnt(8), the wait costs ~150 cycles per tile: measured); all of this wave's
+  // fragment reads of the slots event j is about to overwrite are complete (lgkmcnt 0)
+  MMPL_DEV void barrier() { if constexpr (W64_ABL & 8) return; asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-  // ---------------------------------------------------------------- LDS-DMA (event j = { K(j+4), V(j+2) })
+  // ---------------------------------------------------------------- LDS-DMA (event j = { K(j+4), V(j+3) })
   // A piece = 4 rows x 256 B = one buffer_load_dwordx4 ... lds.  Wave w moves pieces 4w..4w+3 of a tile; M0 (the LDS
   // destination of piece 4w) is written once per tile and the instruction offset -- which the hardware adds to BOTH addresses
   // -- steps the LDS side by 1 KiB per piece (the per-piece source offsets are pre-compensated by - 1024 k).  The source is
@@ -171,7 +172,7 @@ struct Ctx {
     return r;
   }
   // Cursor arithmetic.  Inside a run an iteration only adds kstep / vstep to the scalar offsets (no branch); plan(j), called
-  // between runs, places both cursors for iteration j from scratch (K at tile j + 4, V at j + 2, each parked on the block's last
+  // between runs, places both cursors for iteration j from scratch (K at tile j + 4, V at j + 3, each parked on the block's last
   // tile once it gets there -- that tile is simply re-fetched, so every event issues exactly 8 pieces and the counted waits
   // never change), sets or clears the mask tile for tile j, and returns how many iterations may run before the next event.
   MMPL_DEV void seek_k(int t, int& pos) {
@@ -208,7 +209,7 @@ struct Ctx {
   }
   MMPL_DEV int plan(int j) {
     int n = T - j, pos;
-    const int tk = min(j + 4, T - 1), tv = min(j + 2, T - 1);
+    const int tk = min(j + 4, T - 1), tv = min(j + 3, T - 1);
     seek_k(tk, pos);
     kstep = 0;
     if (tk < T - 1) { kstep = tile_bytes_k; n = min(n, min(tiles_pp - pos, T - tk)); }
@@ -327,24 +328,21 @@ template <int MODE> MMPL_DEV void w64_pass(Ctx& k) {
   k.rk = TILE; k.rv = 0;
   k.kstep = k.vstep = 0;
 
-  // ---- prologue: DMA events -4 .. -1 (event e = { K(e+4), V(e+2) }), then the K(0) fragments
+  // ---- prologue: DMA events -4 .. -1 (event e = { K(e+4), V(e+3) }; V(-1) does not exist), then the K(0) fragments
   int pos;
   k.seek_k(0, pos);
   sfor<4>([&k](auto kk) { k.template dma_k<decltype(kk)::value>(); });
   k.advance_k();
-  k.seek_k(min(1, T - 1), pos);
-  sfor<4>([&k](auto kk) { k.template dma_k<decltype(kk)::value>(); });
-  k.advance_k();
 #pragma unroll 1
-  for (int e = 0; e < 2; ++e) {
-    k.seek_k(min(e + 2, T - 1), pos);
-    k.seek_v(min(e, T - 1), pos);
+  for (int e = 1; e < 4; ++e) {
+    k.seek_k(min(e, T - 1), pos);
+    k.seek_v(min(e - 1, T - 1), pos);
     sfor<4>([&k](auto kk) { k.template dma_k<decltype(kk)::value>(); });
     sfor<4>([&k](auto kk) { k.template dma_v<decltype(kk)::value>(); });
     k.advance_k();
     k.advance_v();
   }
-  asm volatile("s_waitcnt vmcnt(20)\n\ts_barrier" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");        // K(0): the first 4 of the 28 pieces
   k.kaddr = k.kbase;
   sfor<16>([&k](auto gi) { k.template lds_k<decltype(gi)::value>(); });
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

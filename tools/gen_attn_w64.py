@@ -31,14 +31,26 @@ BUDGET = float(os.environ.get("W64_BUDGET", 5.0))
 # ---- fixed fillers: (flag, statement, slots)
 A_FIXED = {g: [] for g in range(32)}
 B_FIXED = {g: [] for g in range(32)}
+# The LDS-DMA pieces of one event (4 K + 4 V per wave; gaps 0..31 = phase A, 32..63 = phase B).  All four waves of the block run
+# the same stream in step (one barrier per tile), so pieces in consecutive gaps arrive at the CU's one address path 4 at a
+# time, 8 times in a row: measured 145 cycles per tile of issue back-pressure; spread out they cost ~0.
+K_DMA = [int(x) for x in os.environ.get("W64_KDMA", "4,8,12,16").split(",")]
+V_DMA = [int(x) for x in os.environ.get("W64_VDMA", "20,24,28,36").split(",")]
+W_DMA = float(os.environ.get("W64_WDMA", BUDGET - 1))
+
+
+def _fixed(g):
+    return A_FIXED[g] if g < 32 else B_FIXED[g - 32]
+
+
 A_FIXED[0].append(("PV", "k.template lds_v<15>();", 2))
 A_FIXED[3].append(("QK", "k.barrier();", BUDGET))
 A_FIXED[3].append(("!QK", "k.wait_lgkm0();", 1))
 for i in range(4):
-    A_FIXED[4 + i].append(("QK", f"k.template dma_k<{i}>();", BUDGET - 1))
-    A_FIXED[8 + i].append(("QK", f"k.template dma_v<{i}>();", BUDGET - 1))
-A_FIXED[19].append(("QK", "k.advance_k();", 2))
-A_FIXED[21].append(("QK", "k.advance_v();", 2))
+    _fixed(K_DMA[i]).append(("QK", f"k.template dma_k<{i}>();", W_DMA))
+    _fixed(V_DMA[i]).append(("QK", f"k.template dma_v<{i}>();", W_DMA))
+_fixed(max(K_DMA) + 3).append(("QK", "k.advance_k();", 1))
+_fixed(max(V_DMA) + 3).append(("QK", "k.advance_v();", 1))
 B_FIXED[0].append(("QK", "k.addr_k();", 1))
 for f in range(16):
     B_FIXED[1 + f].append(("QK", f"k.template lds_k<{f}>();", 1 if f & 1 or f == 0 else 2))
