@@ -36,11 +36,9 @@
 // the page's end, whose K and V rows the LDS-DMA's range check zero-filled).
 #include <stdlib.h>
 
-#include <type_traits>
-#include <utility>
-
 #include "common.h"
 #include "kernels.h"
+#include "w64_util.h"
 
 namespace {
 
@@ -49,15 +47,8 @@ constexpr int W64_SMEM = 2 * RING * TILE + 64;     // + the block's redo flag
 constexpr float BOUND_GEN = 1073741824.f;                              // 2^30: a GENERAL tile's partial row sums
 constexpr float FAST_L_MIN = 9.094947e-13f, FAST_L_MAX = 1.2676506e30f;       // 2^-40, 2^100: a FAST pass's final row sums
 
-template <int I> using ic = std::integral_constant<int, I>;
-template <class F, int... I> MMPL_DEV void sfor_(F&& f, std::integer_sequence<int, I...>) { (f(ic<I>{}), ...); }
-template <int N, class F> MMPL_DEV void sfor(F&& f) { sfor_(f, std::make_integer_sequence<int, N>{}); }
-
-#define A10(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
-#define ALL_AGPRS                                                                                                                  \
-  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", A10(1), A10(2), A10(3), A10(4), A10(5), A10(6), A10(7), A10(8),     \
-      A10(9), A10(10), A10(11), A10(12), A10(13), A10(14), A10(15), A10(16), A10(17), A10(18), A10(19), A10(20), A10(21), A10(22), \
-      A10(23), A10(24), "a250", "a251", "a252", "a253", "a254", "a255"
+using w64::sfor;
+#define ALL_AGPRS MMPL_ALL_AGPRS
 
 constexpr int AO = 0, AQ = 128, AV = 192;      // accumulator-file map
 

@@ -481,6 +481,11 @@ template <int EPI>
 hipError_t launch(const GemmArgs& g, hipStream_t s) {
   // kernel-selection overrides for A/B runs, read once per process
   static const bool env_v1 = getenv("MMPL_GEMM_V1") != nullptr, env_v2 = getenv("MMPL_GEMM_V2") != nullptr;
+  // gemm_w64.hip (one wave per SIMD, 4-deep ring, residual fetched by the k loop's tail) keeps the matrix pipe 85 % busy
+  // inside its k loop but is not faster end to end on this chip (in situ 1174 vs 1213 TFLOP/s: both run against the power
+  // limit, and its idle epilogue does not give the clock back -- DESIGN.md section 3.2), so it is opt-in: MMPL_GEMM_W64=1
+  static const bool env_w64 = getenv("MMPL_GEMM_W64") != nullptr;
+  if (env_w64 && !env_v1 && !env_v2 && mmpl_gemm_w64_accepts(g)) return mmpl_launch_gemm_w64(g, s);
   const bool big = g.batch <= 1 && g.M >= 1024 && g.N >= 256 && g.K >= 128 && !env_v1 && !env_v2;
   // v6 addresses its operands with 32-bit byte offsets from the base pointers; anything larger goes to v2 (64-bit pointers)
   if (big && (long long)g.M * g.lda < (1ll << 31) && (long long)g.N * g.ldw < (1ll << 31)) return launch_v6<EPI>(g, s);

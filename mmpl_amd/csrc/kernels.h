@@ -30,6 +30,8 @@ struct GemmArgs {
   bf16_t* v_dst[8]; int v_col0, v_ld;
 };
 hipError_t mmpl_launch_gemm(const GemmArgs& g, hipStream_t s);
+bool mmpl_gemm_w64_accepts(const GemmArgs& g);                      // gemm_w64.hip: the one-wave-per-SIMD kernel for the large linears
+hipError_t mmpl_launch_gemm_w64(const GemmArgs& g, hipStream_t s);
 
 // ---------------------------------------------------------------- attention (attention.hip)
 constexpr int MMPL_MAX_PAGES = 24;

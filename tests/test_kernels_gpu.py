@@ -57,6 +57,20 @@ def test_gemm(lib, M, N, K, epi):
     assert bf16_ulp_frac(Cc, y, 2) < 2e-3
 
 
+def test_gemm_w64_opt_in_kernel():
+    """gemm_w64.hip (one wave per SIMD) is opt-in through MMPL_GEMM_W64, read once per process: run the GEMM cases and a DiT
+    forward (its EPI_BIAS_VPAGES epilogue) in a child process with it set."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MMPL_GEMM_W64="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_kernels_gpu.py", "tests/test_dit_forward_gpu.py",
+                        "-k", "(test_gemm and not w64) or golden"], cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_gemm_heavy_tailed(lib):
     """Wan-like activation statistics: a few channels of A carry values ~100x the rest (massive activations) and a few
     weight rows are large; same tolerance as test_gemm (the fp32 accumulation must not lose the small terms)."""

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build attn_w64.hip with -save-temps in a scratch dir and audit the ISA (CDNA guide 5.7 item 4): the kernel owns a[0:255] by
 name, so the build is only valid if the compiler never touches the accumulator file itself, spills nothing and uses no scratch.
-    python tools/audit_w64.py [--keep DIR]"""
+    python tools/audit_w64.py [--src gemm_w64.hip] [--keep DIR]"""
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -60,13 +60,16 @@ def audit(workdir, src=SRC, own_agprs=True):
 
 
 if __name__ == "__main__":
+    src = SRC
+    if "--src" in sys.argv:
+        src = os.path.join(ROOT, "mmpl_amd", "csrc", sys.argv[sys.argv.index("--src") + 1])
     if "--keep" in sys.argv:
         d = sys.argv[sys.argv.index("--keep") + 1]
         os.makedirs(d, exist_ok=True)
-        problems, info = audit(d)
+        problems, info = audit(d, src)
     else:
         with tempfile.TemporaryDirectory() as d:
-            problems, info = audit(d)
+            problems, info = audit(d, src)
     print(info)
     for p in problems:
         print("PROBLEM:", p)

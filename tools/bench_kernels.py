@@ -65,10 +65,53 @@ def bench_gemm(iters):
         print(f"gemm {name}: M={M} N={N} K={K} epi={epi}  {ms:8.3f} ms  {2.0 * M * N * K / ms / 1e9:8.1f} TFLOP/s", flush=True)
 
 
+def gemm_phases(epi=3):
+    """needs a -DGEMM_ABL=32 build: per-wave { prologue, k loop, epilogue } cycles written over the output"""
+    M, N, K = 25200, 5120, 5120
+    A = torch.randn(M, K, device=dev).to(BF)
+    W = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(BF)
+    b = torch.randn(N, device=dev).to(BF)
+    Cc = torch.zeros(M, N, device=dev, dtype=BF)
+    res = torch.randn(M, N, device=dev).to(BF)
+    gate = torch.randn(8, N, device=dev).to(BF)
+    for _ in range(2):
+        _lib.check(lib.mmpl_gemm(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(Cc), N, M, N, K, epi, _lib.ptr(res), N, _lib.ptr(gate), N,
+                                 3600, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    nblk = ((M + 255) // 256) * (N // 256)
+    t = Cc.view(-1).view(torch.float32)[: nblk * 16].view(-1, 4).double()
+    t = t[t[:, 3] == K // 32]
+    print(f"gemmphases epi={epi}: waves {len(t)}  prologue {t[:, 0].mean().item():.0f}  loop {t[:, 1].mean().item():.0f} "
+          f"({t[:, 1].mean().item() / (K // 32) / 32:.2f} per MFMA)  epilogue {t[:, 2].mean().item():.0f} (max {t[:, 2].max().item():.0f}) cycles", flush=True)
+
+
+def gemm_cycles():
+    """needs a -DGEMM_ABL=16|... build of gemm_w64.hip: per-wave cycle counts of the k loop instead of C"""
+    M, N, K = 25200, 5120, 5120
+    A = torch.randn(M, K, device=dev).to(BF)
+    W = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(BF)
+    b = torch.randn(N, device=dev).to(BF)
+    Cc = torch.zeros(M, N, device=dev, dtype=BF)
+    for _ in range(3):
+        _lib.check(lib.mmpl_gemm(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(Cc), N, M, N, K, 0, None, N, None, N, 3600, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    nblk = ((M + 255) // 256) * (N // 256)
+    t = Cc.view(-1).view(torch.float32)[: nblk * 8].view(-1, 2).double()
+    t = t[t[:, 1] > 0]
+    per = t[:, 0] / t[:, 1]
+    print(f"gemmcycles M={M} N={N} K={K}: waves {len(per)} stages {t[0, 1].item():.0f} cycles/stage mean {per.mean().item():.1f} min {per.min().item():.1f} "
+          f"max {per.max().item():.1f} -> {per.mean().item() / 32:.2f} cycles per MFMA", flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 5
     if what in ("attn", "all"):
         bench_attn(iters)
+    if what == "gemmcycles":
+        gemm_cycles()
+    if what == "gemmphases":
+        gemm_phases(3)
+        gemm_phases(0)
     if what in ("gemm", "all"):
         bench_gemm(iters)
