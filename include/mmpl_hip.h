@@ -49,9 +49,17 @@ size_t mmpl_dit_context_workspace_bytes(const MmplDit* h);
 int mmpl_dit_precompute_context(MmplDit* h, const void* context, void* cross_k, void* cross_v, void* workspace,
                                 size_t workspace_bytes, mmpl_stream_t stream);
 
+/* Wan-I2V model type (WanModel(model_type='i2v'), wan/modules/model.py:563-616,672-712): in_dim = 36 (x and the
+ * conditioning video y concatenated on the channel axis, model.py:680-681 -- the caller concatenates) and every block's
+ * cross-attention also attends to the 257 projected CLIP tokens (WanI2VCrossAttention, model.py:224-266).  The image
+ * K / V depend only on the image: img_k[l] = norm_k_img(k_img(img_emb(clip_fea))), img_v[l] = v_img(...), built with
+ * mmpl_i2v_img_proj + mmpl_i2v_img_kv per layer; dev [num_layers, n_img_tokens, dim], borrowed until replaced.
+ * NULL, NULL restores the text-only cross-attention. */
+int mmpl_dit_set_image_kv(MmplDit* h, const void* img_k, const void* img_v, int n_img_tokens);
+
 /* CausalFPSWanModel._forward_inference (causal_fps_model.py:708-837) behind WanFPSWrapper.forward
  * (utils/wan_wrapper.py:422-493).
- *   x_in / out : dev [n_frames, 16, lat_h, lat_w]  (the pipeline's [B=1, F, C, H, W] layout)
+ *   x_in / out : dev [n_frames, in_dim, lat_h, lat_w] / [n_frames, 16, lat_h, lat_w]  (the pipeline's [B=1, F, C, H, W] layout)
  *   t_dev      : dev float32 [n_frames]
  *   frame_ids  : host, RoPE temporal index per frame (= current_start / frame_seqlen)
  *   write_slots: host, KV slot each frame's K/V is written to before attending; all -1 = do not persist

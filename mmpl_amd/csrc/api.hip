@@ -86,9 +86,16 @@ static const char* kLayerNames[NL] = {
     "cross_attn.norm_k.weight", "cross_attn.v.weight", "cross_attn.v.bias", "cross_attn.o.weight", "cross_attn.o.bias",
     "ffn.0.weight", "ffn.0.bias", "ffn.2.weight", "ffn.2.bias"};
 
+enum { I_K_W, I_K_B, I_V_W, I_V_B, I_NK, NI };   // per-layer slots of the Wan-I2V image stream (cross_attn.{k_img,v_img,norm_k_img})
+
 struct MmplDit {
   MmplDitConfig cfg;
   int S, gh, gw;
+  int pe_k;                    // K of the patch-embedding GEMM: 4 * in_dim rounded up to a multiple of 64 (64 | 192)
+  // Wan-I2V (model_type 'i2v', model.py:595,615-616): per-layer image K / V of the current image, [num_layers, n_img, dim]
+  const bf16_t* img_k = nullptr;
+  const bf16_t* img_v = nullptr;
+  int n_img = 0;
   float* cos_tab = nullptr;  // [1024][64]
   float* sin_tab = nullptr;
   std::vector<const bf16_t*> w;
@@ -132,13 +139,14 @@ int mmpl_dit_create(const MmplDitConfig* cfg, MmplDit** out) {
     return fail("mmpl_dit_create", "head_dim must be 128 (both Wan2.1 models)");
   if (cfg->dim > 5120 || cfg->dim % 128 || cfg->ffn_dim % 64 || cfg->text_dim % 64 || cfg->freq_dim % 64)
     return fail("mmpl_dit_create", "unsupported dims");
-  if (cfg->lat_h % 2 || cfg->lat_w % 2 || cfg->max_frames < 1 || cfg->max_frames > 8 || cfg->in_dim != 16 || cfg->out_dim != 16)
+  if (cfg->lat_h % 2 || cfg->lat_w % 2 || cfg->max_frames < 1 || cfg->max_frames > 8 || (cfg->in_dim != 16 && cfg->in_dim != 36) || cfg->out_dim != 16)
     return fail("mmpl_dit_create", "unsupported geometry");
   MmplDit* h = new MmplDit();
   h->cfg = *cfg;
   h->gh = cfg->lat_h / 2;
   h->gw = cfg->lat_w / 2;
   h->S = h->gh * h->gw;
+  h->pe_k = (4 * cfg->in_dim + 63) / 64 * 64;
   // RoPE tables: rope_params(1024, d - 4*(d//6)) | (1024, 2*(d//6)) x2, theta 1e4, fp64 (model.py:29-36,
   // causal_fps_model.py:510-516), stored as fp32 cos / sin.
   const int d = 128, dims[3] = {d - 4 * (d / 6), 2 * (d / 6), 2 * (d / 6)};
@@ -211,7 +219,7 @@ FwdWs carve_fwd(const MmplDit* h, int nF, void* base) {
   w.attn = k.take(Lq * d);
   w.ksc = k.take(Lq * d);
   w.vsc = k.take(Lq * d);
-  w.patch = k.take(Lq * 64);
+  w.patch = k.take(Lq * (size_t)h->pe_k);
   w.sinu = k.take((size_t)nF * c.freq_dim);
   w.t1 = k.take((size_t)nF * d);
   w.e = k.take((size_t)nF * d);
@@ -265,6 +273,16 @@ int mmpl_dit_precompute_context(MmplDit* h, const void* context, void* cross_k, 
   return 0;
 }
 
+int mmpl_dit_set_image_kv(MmplDit* h, const void* img_k, const void* img_v, int n_img_tokens) {
+  if (!h) return fail("mmpl_dit_set_image_kv", "null handle");
+  if ((img_k == nullptr) != (img_v == nullptr)) return fail("mmpl_dit_set_image_kv", "need both of img_k / img_v, or neither");
+  if (img_k && (n_img_tokens < 1 || n_img_tokens > 4096)) return fail("mmpl_dit_set_image_kv", "n_img_tokens out of range");
+  h->img_k = (const bf16_t*)img_k;
+  h->img_v = (const bf16_t*)img_v;
+  h->n_img = img_k ? n_img_tokens : 0;
+  return 0;
+}
+
 int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, const int* frame_ids,
                      const int* write_slots, const int* visible_slots, int n_visible, void* k_cache, void* v_cache,
                      int n_slots, const void* cross_k, const void* cross_v, void* out, void* workspace,
@@ -289,8 +307,8 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
   const int S = h->S, d = c.dim, f = c.ffn_dim, Lq = nF * S, H = c.num_heads, T = c.text_len;
 
   // ---- embeddings (causal_fps_model.py:757-776)
-  HIP_TRY(mmpl_launch_patchify((const bf16_t*)x_in, w.patch, nF, c.in_dim, c.lat_h, c.lat_w, s), "patchify");
-  TRY(gemm(w.patch, 64, h->G(G_PE_W), 64, h->G(G_PE_B), w.x, d, Lq, d, 64, EPI_BIAS, nullptr, 0, nullptr, 0, 1, s));
+  HIP_TRY(mmpl_launch_patchify((const bf16_t*)x_in, w.patch, h->pe_k, nF, c.in_dim, c.lat_h, c.lat_w, s), "patchify");
+  TRY(gemm(w.patch, h->pe_k, h->G(G_PE_W), h->pe_k, h->G(G_PE_B), w.x, d, Lq, d, h->pe_k, EPI_BIAS, nullptr, 0, nullptr, 0, 1, s));
   HIP_TRY(mmpl_launch_sinusoid(t_dev, w.sinu, nF, c.freq_dim, s), "sinusoid");
   TRY(gemm(w.sinu, c.freq_dim, h->G(G_TE0_W), c.freq_dim, h->G(G_TE0_B), w.t1, d, nF, d, c.freq_dim, EPI_BIAS_SILU, nullptr,
            0, nullptr, 0, 1, s));
@@ -382,6 +400,17 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
       a.v_pages[0] = (const bf16_t*)cross_v + (size_t)l * T * d;
       ProfScope ps(K_ATTN_CROSS, 4.0 * Lq * (double)T * d, s);
       HIP_TRY(mmpl_launch_attention(a, s), "cross attention");
+      if (h->img_k) {
+        // Wan-I2V: the query also attends to the image tokens; the two outputs are summed in bf16 before the o-projection
+        // (WanI2VCrossAttention.forward, model.py:254-263).  The scratch K pages are free here: they hold the image output.
+        a.o = w.ksc;
+        a.page_rows = h->n_img;
+        a.k_pages[0] = h->img_k + (size_t)l * h->n_img * d;
+        a.v_pages[0] = h->img_v + (size_t)l * h->n_img * d;
+        ProfScope ps2(K_ATTN_CROSS, 4.0 * Lq * (double)h->n_img * d, s);
+        HIP_TRY(mmpl_launch_attention(a, s), "image cross attention");
+        HIP_TRY(mmpl_launch_add(w.attn, w.ksc, (size_t)Lq * d, s), "x + img_x");
+      }
     }
     TRY(gemm(w.attn, d, h->Lw(l, L_CO_W), d, h->Lw(l, L_CO_B), w.x, d, Lq, d, d, EPI_RES, w.x, d, nullptr, 0, 1, s));
     // -- FFN (causal_fps_model.py:354-360)

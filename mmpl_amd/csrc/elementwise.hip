@@ -165,15 +165,15 @@ __global__ void modulation_kernel(const bf16_t* mod, size_t mod_layer_stride, co
   }
 }
 
-__global__ void patchify_kernel(const bf16_t* x, bf16_t* a, int F, int C, int h, int w) {
+__global__ void patchify_kernel(const bf16_t* x, bf16_t* a, int lda, int F, int C, int h, int w) {
   const int gh = h >> 1, gw = w >> 1;
-  const size_t total = (size_t)F * gh * gw * C * 4;
+  const size_t total = (size_t)F * gh * gw * lda;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int col = (int)(i % (C * 4));
-    const size_t tokg = i / (C * 4);
+    const int col = (int)(i % lda);
+    const size_t tokg = i / lda;
     const int c = col >> 2, ph = (col >> 1) & 1, pw = col & 1;
     const int gx = (int)(tokg % gw), gy = (int)((tokg / gw) % gh), f = (int)(tokg / ((size_t)gw * gh));
-    a[i] = x[(((size_t)f * C + c) * h + (2 * gy + ph)) * w + 2 * gx + pw];
+    a[i] = c < C ? x[(((size_t)f * C + c) * h + (2 * gy + ph)) * w + 2 * gx + pw] : (bf16_t)0;      // columns >= 4 C: K padding
   }
 }
 
@@ -307,9 +307,9 @@ hipError_t mmpl_launch_modulation(const bf16_t* mod, size_t mod_layer_stride, co
                      n_layers, n_frames, nmod, d);
   return hipGetLastError();
 }
-hipError_t mmpl_launch_patchify(const bf16_t* x, bf16_t* a, int F, int C, int h, int w, hipStream_t s) {
-  const size_t n = (size_t)F * C * h * w;
-  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, a, F, C, h, w);
+hipError_t mmpl_launch_patchify(const bf16_t* x, bf16_t* a, int lda, int F, int C, int h, int w, hipStream_t s) {
+  const size_t n = (size_t)F * (h / 2) * (w / 2) * lda;
+  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, a, lda, F, C, h, w);
   return hipGetLastError();
 }
 hipError_t mmpl_launch_unpatchify(const bf16_t* y, int ldy, bf16_t* out, int F, int C, int h, int w, hipStream_t s) {

@@ -47,6 +47,11 @@ int blocks_for(size_t n) { return (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255
 
 }  // namespace
 
+hipError_t mmpl_launch_add(bf16_t* a, const bf16_t* b, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(add_kernel, dim3(blocks_for(n)), dim3(256), 0, s, a, b, n);
+  return hipGetLastError();
+}
+
 extern "C" {
 
 size_t mmpl_i2v_img_proj_workspace_bytes(int n_tok, int clip_dim, int dim) {

@@ -98,9 +98,11 @@ hipError_t mmpl_launch_rmsnorm(bf16_t* x, int ldx, const bf16_t* w, int rows, in
 // emod[l][f][k][:] = bf16(mod[l*mod_layer_stride + k*d + :] + e[f*e_frame_stride + (bcast ? : : k*d + :)])   (k < nmod)
 hipError_t mmpl_launch_modulation(const bf16_t* mod, size_t mod_layer_stride, const bf16_t* e, int e_frame_stride, int bcast,
                                   bf16_t* emod, int n_layers, int n_frames, int nmod, int d, hipStream_t s);
-// patchify: x[F, C=16, h, w] -> A[F*gh*gw, 64]  (col = c*4 + ph*2 + pw)
-hipError_t mmpl_launch_patchify(const bf16_t* x, bf16_t* a, int F, int C, int h, int w, hipStream_t s);
+// patchify: x[F, C, h, w] -> A[F*gh*gw, lda]  (col = c*4 + ph*2 + pw; columns >= 4 C are zero: K padded to a multiple of 64)
+hipError_t mmpl_launch_patchify(const bf16_t* x, bf16_t* a, int lda, int F, int C, int h, int w, hipStream_t s);
 // unpatchify: y[F*gh*gw, 4*C] (col = (ph*2+pw)*C + c) -> out[F, C, h, w]
+// a = bf16(a + b), n elements (i2v.hip)
+hipError_t mmpl_launch_add(bf16_t* a, const bf16_t* b, size_t n, hipStream_t s);
 hipError_t mmpl_launch_unpatchify(const bf16_t* y, int ldy, bf16_t* out, int F, int C, int h, int w, hipStream_t s);
 // sinusoidal timestep embedding (fp64 math): t[F] fp32 -> out[F, freq_dim] bf16 ([cos | sin])
 hipError_t mmpl_launch_sinusoid(const float* t, bf16_t* out, int F, int freq_dim, hipStream_t s);

@@ -3,6 +3,11 @@
 Mirrors what ``CausalFPSWanModel`` (MMPL_t2v/wan/modules/causal_fps_model.py:398-530, 708-837) offers the
 wrapper: construct from the model dims, ``load_state_dict`` with the reference's keys, run one inference
 forward against a per-layer KV cache.  PyTorch only owns the device memory here; all compute is in the library.
+
+``model_type='i2v'`` (wan/modules/model.py:563-616: in_dim 36, ``img_emb`` = MLPProj(1280, dim), every block's
+cross-attention a ``WanI2VCrossAttention``) adds the image stream: ``precompute_image_context(clip_fea)`` builds the
+per-layer image K / V once per image, ``set_image_kv`` attaches them, and ``forward`` takes x with the conditioning video
+``y`` concatenated on the channel axis (model.py:680-681).
 """
 from __future__ import annotations
 
@@ -29,11 +34,15 @@ class DitEngine:
         self.text_len = cfg.get("text_len", 512)
         self.text_dim = cfg.get("text_dim", 4096)
         self.max_frames = max_frames
+        self.model_type = cfg.get("model_type", "t2v")
+        assert self.model_type in ("t2v", "i2v")
+        self.in_dim = cfg.get("in_dim", 36 if self.model_type == "i2v" else 16)
+        self.clip_dim = cfg.get("clip_dim", 1280)
         lib = _lib.load()
         self._lib = lib
         c = _lib.MmplDitConfig(dim=cfg["dim"], ffn_dim=cfg["ffn_dim"], num_heads=cfg["num_heads"],
                                num_layers=cfg["num_layers"], text_dim=self.text_dim, freq_dim=cfg.get("freq_dim", 256),
-                               in_dim=16, out_dim=16, text_len=self.text_len, eps=cfg.get("eps", 1e-6), lat_h=lat_h,
+                               in_dim=self.in_dim, out_dim=16, text_len=self.text_len, eps=cfg.get("eps", 1e-6), lat_h=lat_h,
                                lat_w=lat_w, max_frames=max_frames)
         self._c = c
         h = C.c_void_p()
@@ -43,6 +52,8 @@ class DitEngine:
         self._weights: List[torch.Tensor] = []
         self._ws: Dict[int, torch.Tensor] = {}
         self._ctx_ws: Optional[torch.Tensor] = None
+        self._i2v_w: Optional[dict] = None                 # img_emb + per-layer k_img / v_img / norm_k_img (model_type 'i2v')
+        self._img_kv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
 
     def __del__(self):
         try:
@@ -65,7 +76,10 @@ class DitEngine:
         for k in _GLOBAL_KEYS:
             t = g(k)
             if k == "patch_embedding.weight":
-                t = t.reshape(t.shape[0], -1).contiguous()
+                t = t.reshape(t.shape[0], -1)
+                pe_k = (t.shape[1] + 63) // 64 * 64         # K of the patch GEMM: 4 * in_dim padded to a multiple of 64 (zeros)
+                assert t.shape[1] == 4 * self.in_dim, (tuple(t.shape), self.in_dim)
+                t = torch.nn.functional.pad(t, (0, pe_k - t.shape[1])).contiguous()
             w.append(t)
         w.append(torch.stack([g(f"blocks.{i}.modulation").reshape(6, self.dim) for i in range(self.L)]).contiguous())
         for i in range(self.L):
@@ -83,6 +97,12 @@ class DitEngine:
         arr = (C.c_void_p * n)(*[t.data_ptr() for t in w])
         _lib.check(self._lib.mmpl_dit_bind_weights(self._h, arr, n), "mmpl_dit_bind_weights")
         self._weights = w      # keep alive: the library borrows the pointers
+        if self.model_type == "i2v":
+            self._i2v_w = dict(
+                img_emb=[g("img_emb." + k) for k in ("proj.0.weight", "proj.0.bias", "proj.1.weight", "proj.1.bias", "proj.3.weight",
+                                                     "proj.3.bias", "proj.4.weight", "proj.4.bias")],
+                layers=[[g(f"blocks.{i}.cross_attn." + k) for k in ("k_img.weight", "k_img.bias", "v_img.weight", "v_img.bias",
+                                                                     "norm_k_img.weight")] for i in range(self.L)])
 
     # ------------------------------------------------------------------ caches
     def new_kv_cache(self, n_slots: int = 15) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -104,6 +124,40 @@ class DitEngine:
                                                          self._ctx_ws.numel(), _lib.stream_ptr()), "precompute_context")
         return ck, cv
 
+    def precompute_image_context(self, clip_fea: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """clip_fea: [257, clip_dim] (CLIP ViT-H penultimate-block tokens, clip.py:541) -> per-layer image (K, V)
+        [num_layers, 257, dim]: img_emb (MLPProj, model.py:469-481), then k_img / norm_k_img and v_img of every block
+        (model.py:251-252).  Once per image, like precompute_context once per prompt."""
+        if self._i2v_w is None:
+            raise RuntimeError("DitEngine: not an i2v model (or weights not loaded)")
+        lib, d = self._lib, self.dim
+        fea = clip_fea.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        n = fea.shape[0]
+        assert fea.shape == (n, self.clip_dim)
+        ctx_img = torch.empty(n, d, dtype=torch.bfloat16, device=self.device)
+        ws = torch.empty(lib.mmpl_i2v_img_proj_workspace_bytes(n, self.clip_dim, d), dtype=torch.uint8, device=self.device)
+        arr = (C.c_void_p * 8)(*[t.data_ptr() for t in self._i2v_w["img_emb"]])
+        img_k = torch.empty(self.L, n, d, dtype=torch.bfloat16, device=self.device)
+        img_v = torch.empty_like(img_k)
+        with torch.cuda.device(self.device):
+            _lib.check(lib.mmpl_i2v_img_proj(_lib.ptr(fea), n, self.clip_dim, d, arr, _lib.ptr(ctx_img), _lib.ptr(ws), ws.numel(),
+                                             _lib.stream_ptr()), "mmpl_i2v_img_proj")
+            for l, (kw, kb, vw, vb, nk) in enumerate(self._i2v_w["layers"]):
+                _lib.check(lib.mmpl_i2v_img_kv(_lib.ptr(ctx_img), n, d, _lib.ptr(kw), _lib.ptr(kb), _lib.ptr(vw), _lib.ptr(vb), _lib.ptr(nk),
+                                               self.cfg.get("eps", 1e-6), _lib.ptr(img_k[l]), _lib.ptr(img_v[l]), _lib.stream_ptr()),
+                           "mmpl_i2v_img_kv")
+        return img_k, img_v
+
+    def set_image_kv(self, img_k: Optional[torch.Tensor], img_v: Optional[torch.Tensor]) -> None:
+        """Attach (or, with None, detach) the per-layer image K / V that every later forward's cross-attention also attends to."""
+        if img_k is None:
+            _lib.check(self._lib.mmpl_dit_set_image_kv(self._h, None, None, 0), "mmpl_dit_set_image_kv")
+            self._img_kv = None
+            return
+        assert img_k.shape == img_v.shape and img_k.shape[0] == self.L and img_k.shape[2] == self.dim and img_k.is_contiguous()
+        _lib.check(self._lib.mmpl_dit_set_image_kv(self._h, _lib.ptr(img_k), _lib.ptr(img_v), img_k.shape[1]), "mmpl_dit_set_image_kv")
+        self._img_kv = (img_k, img_v)      # keep alive: the library borrows the pointers
+
     def workspace(self, n_frames: int) -> torch.Tensor:
         if n_frames not in self._ws:
             nbytes = self._lib.mmpl_dit_workspace_bytes(self._h, n_frames)
@@ -119,14 +173,17 @@ class DitEngine:
     def forward(self, x: torch.Tensor, t: torch.Tensor, frame_ids: Sequence[int], write_slots: Sequence[int],
                 visible_slots: Sequence[int], k_cache: torch.Tensor, v_cache: torch.Tensor, cross_k: torch.Tensor,
                 cross_v: torch.Tensor, out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """x: [nF, 16, lat_h, lat_w] bf16; t: [nF] float32 (device).  Returns flow prediction, same shape as x.
+        """x: [nF, in_dim, lat_h, lat_w] bf16 (i2v: x and y concatenated on the channel axis); t: [nF] float32 (device).
+        Returns the flow prediction [nF, 16, lat_h, lat_w].
         `workspace`: a private scratch buffer (>= workspace_bytes(nF)) for a forward that runs concurrently with another
         one on a different stream (cond / uncond); default: the engine's own."""
         nF = x.shape[0]
-        assert x.is_contiguous() and x.dtype == torch.bfloat16 and x.shape[1:] == (16, self.lat_h, self.lat_w)
+        assert x.is_contiguous() and x.dtype == torch.bfloat16 and x.shape[1:] == (self.in_dim, self.lat_h, self.lat_w)
         assert t.dtype == torch.float32 and t.numel() == nF and t.is_cuda
+        if self.model_type == "i2v" and self._img_kv is None:
+            raise RuntimeError("DitEngine: an i2v model needs set_image_kv(*precompute_image_context(clip_fea)) before forward")
         if out is None:
-            out = torch.empty_like(x)
+            out = torch.empty(nF, 16, self.lat_h, self.lat_w, dtype=torch.bfloat16, device=x.device)
         ws = self.workspace(nF) if workspace is None else workspace
         n_slots = k_cache.shape[1] // self.S
         ia = lambda v: (C.c_int * len(v))(*[int(i) for i in v])

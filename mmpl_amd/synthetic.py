@@ -69,6 +69,22 @@ def dit_state_dict(cfg: dict, seed: int = 0, dtype=torch.bfloat16, device="cpu")
     return sd
 
 
+def dit_i2v_state_dict(cfg: dict, seed: int = 0, clip_dim: int = 1280, dtype=torch.bfloat16, device="cpu"):
+    """state_dict of WanModel(model_type='i2v') (MMPL_t2v/wan/modules/model.py:563-616): the t2v keys with in_dim 36, plus
+    ``img_emb`` (MLPProj) and every block's ``cross_attn.{k_img, v_img, norm_k_img}``."""
+    cfg = dict(cfg, in_dim=cfg.get("in_dim", 36))
+    sd = dit_state_dict({k: v for k, v in cfg.items() if k != "model_type"}, seed=seed, dtype=dtype, device=device)
+    dim = cfg["dim"]
+    for i in range(cfg["num_layers"]):
+        ca, _ = i2v_cross_state_dict(dim, clip_dim, seed=seed * 1000 + 17 + i, dtype=dtype, device=device)
+        for k in ("k_img.weight", "k_img.bias", "v_img.weight", "v_img.bias", "norm_k_img.weight"):
+            sd[f"blocks.{i}.cross_attn.{k}"] = ca[k]
+    _, mp = i2v_cross_state_dict(dim, clip_dim, seed=seed * 1000 + 7, dtype=dtype, device=device)
+    for k, v in mp.items():
+        sd["img_emb." + k] = v
+    return sd
+
+
 def philox_normal(shape, seed: int, dtype=torch.bfloat16) -> torch.Tensor:
     """Build-owned counter-based N(0,1) generator (numpy Philox) so CPU container and GPU box regenerate
     identical inputs without the reference (RNG note)."""

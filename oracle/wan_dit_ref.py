@@ -171,16 +171,28 @@ def self_attention(p, cfg: DitCfg, layer: int, x: torch.Tensor, kv: Dict[str, to
     return _lin(out.flatten(2), p, pre + "o")
 
 
-def cross_attention(p, cfg: DitCfg, layer: int, x: torch.Tensor, ck: torch.Tensor, cv: torch.Tensor, attn_fn=sdpa):
-    """model.py:161-194 with the K/V cache already initialised."""
+def image_kv(p, cfg: DitCfg, layer: int, ctx_img: torch.Tensor):
+    """WanI2VCrossAttention (model.py:251-252): K (RMS-normed) / V of the projected CLIP tokens, [1, 257, N, D]."""
+    pre = f"blocks.{layer}.cross_attn."
+    n, d = cfg.num_heads, cfg.head_dim
+    k = rms_norm(_lin(ctx_img, p, pre + "k_img"), p[pre + "norm_k_img.weight"], cfg.eps).view(1, -1, n, d)
+    v = _lin(ctx_img, p, pre + "v_img").view(1, -1, n, d)
+    return k, v
+
+
+def cross_attention(p, cfg: DitCfg, layer: int, x: torch.Tensor, ck: torch.Tensor, cv: torch.Tensor, attn_fn=sdpa, img=None):
+    """model.py:161-194 with the K/V cache already initialised; img = (k_img, v_img): the Wan-I2V form (model.py:238-266),
+    whose image attention output is added (in bf16) before the o-projection."""
     pre = f"blocks.{layer}.cross_attn."
     q = rms_norm(_lin(x, p, pre + "q"), p[pre + "norm_q.weight"], cfg.eps).view(1, -1, cfg.num_heads, cfg.head_dim)
-    out = attn_fn(q, ck, cv)
-    return _lin(out.flatten(2), p, pre + "o")
+    out = attn_fn(q, ck, cv).flatten(2)
+    if img is not None:
+        out = out + attn_fn(q, img[0], img[1]).flatten(2)
+    return _lin(out, p, pre + "o")
 
 
 def block_forward(p, cfg: DitCfg, layer: int, x, e0, kv, ck, cv, frame_ids, write_slots, visible_slots, S, gh, gw,
-                  freqs, attn_fn=sdpa):
+                  freqs, attn_fn=sdpa, img=None):
     """causal_fps_model.py:335-364."""
     nF = e0.shape[1]
     pre = f"blocks.{layer}."
@@ -191,7 +203,7 @@ def block_forward(p, cfg: DitCfg, layer: int, x, e0, kv, ck, cv, frame_ids, writ
         kv, frame_ids, write_slots, visible_slots, S, gh, gw, freqs, attn_fn)
     x = x + (y.unflatten(dim=1, sizes=(nF, S)) * e[2]).flatten(1, 2)
     x = x + cross_attention(p, cfg, layer, layer_norm(x, cfg.eps, p[pre + "norm3.weight"], p[pre + "norm3.bias"]),
-                            ck, cv, attn_fn)
+                            ck, cv, attn_fn, img)
     h = (layer_norm(x, cfg.eps).unflatten(dim=1, sizes=(nF, S)) * (1 + e[4]) + e[3]).flatten(1, 2)
     y = _lin(F.gelu(_lin(h, p, pre + "ffn.0"), approximate="tanh"), p, pre + "ffn.2")
     x = x + (y.unflatten(dim=1, sizes=(nF, S)) * e[5]).flatten(1, 2)
@@ -221,11 +233,13 @@ def new_kv_cache(cfg: DitCfg, n_slots: int, S: int, dtype=torch.bfloat16):
 def dit_forward(p: Dict[str, torch.Tensor], cfg: DitCfg, x: torch.Tensor, t: torch.Tensor, context: torch.Tensor,
                 kv_cache: List[Dict[str, torch.Tensor]], cross_cache: List[Optional[tuple]], frame_ids: Sequence[int],
                 write_slots: Sequence[int], visible_slots: Sequence[int], attn_fn=sdpa,
-                return_hidden: bool = False) -> torch.Tensor:
+                return_hidden: bool = False, clip_fea: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One inference forward (causal_fps_model.py:708-837).
 
     x: [in_dim, nF, h, w]; t: [1, nF] float32; context: [L<=text_len, text_dim];
     cross_cache[layer] is None (-> filled, model.py:175-180) or (k, v).  Returns [out_dim, nF, h, w].
+    clip_fea [257, 1280]: Wan-I2V model type (model.py:672-712) -- x already carries the conditioning video on its channel
+    axis (in_dim 36), the CLIP tokens go through img_emb (MLPProj) and every block's cross-attention also attends to them.
     """
     nF, gh, gw = x.shape[1], x.shape[2] // 2, x.shape[3] // 2
     S = gh * gw
@@ -234,12 +248,16 @@ def dit_forward(p: Dict[str, torch.Tensor], cfg: DitCfg, x: torch.Tensor, t: tor
     h = h.flatten(2).transpose(1, 2)                                   # [1, nF*S, dim]
     e, e0 = time_embed(p, cfg, t, h)
     ctx = embed_context(p, cfg, context)
+    ctx_img = None
+    if clip_fea is not None:
+        from .i2v_ref import mlp_proj
+        ctx_img = mlp_proj({k[len("img_emb."):]: v for k, v in p.items() if k.startswith("img_emb.")}, clip_fea.unsqueeze(0))
     for layer in range(cfg.num_layers):
         if cross_cache[layer] is None:
             cross_cache[layer] = cross_kv(p, cfg, layer, ctx)
         ck, cv = cross_cache[layer]
         h = block_forward(p, cfg, layer, h, e0, kv_cache[layer], ck, cv, frame_ids, write_slots, visible_slots,
-                          S, gh, gw, freqs, attn_fn)
+                          S, gh, gw, freqs, attn_fn, image_kv(p, cfg, layer, ctx_img) if ctx_img is not None else None)
     if return_hidden:
         return h
     y = head_forward(p, cfg, h, e.unflatten(dim=0, sizes=t.shape).unsqueeze(2), nF, S)

@@ -53,3 +53,40 @@ def test_i2v_cross_attention_production_dims_vs_oracle():
     e = rel_l2(got, want)
     print(f"i2v cross-attention dim 1536, Lq {Lq}: rel_l2(HIP, oracle) = {e:.3e}")
     assert e < 2e-2
+
+
+def test_i2v_model_type_forward_vs_reference_golden():
+    """DitEngine(model_type='i2v') -- in_dim 36, img_emb, image K/V stream in every block's cross-attention -- vs the
+    reference's WanModel(model_type='i2v') forward (tests/golden/dit_i2v_tiny.pt).  Stated tolerance: rel-L2 <= 2e-2."""
+    from mmpl_amd.dit import DitEngine
+    from mmpl_amd.synthetic import WAN_CONFIGS, dit_i2v_state_dict
+    from tests.test_oracle_golden import _i2v_model_inputs
+    fx = torch.load(f"{GOLDEN}/dit_i2v_tiny.pt")
+    m = fx["meta"]
+    cfg = dict(WAN_CONFIGS[m["cfg"]], model_type="i2v")
+    F_, h, w = m["F"], m["lat_h"], m["lat_w"]
+    eng = DitEngine(cfg, h, w, max_frames=F_)
+    eng.load_state_dict(dit_i2v_state_dict(cfg, seed=m["weight_seed"]))
+    x, y, clip_fea, txt = _i2v_model_inputs(m)
+    xin = torch.cat([x, y], dim=0).permute(1, 0, 2, 3).contiguous().cuda()              # [F, 36, h, w]
+    t = torch.full([F_], m["t"], dtype=torch.float32, device="cuda")
+    ck, cv = eng.precompute_context(txt.cuda())
+    kc, vc = eng.new_kv_cache(F_)
+    fr = list(range(F_))
+    with pytest.raises(RuntimeError, match="set_image_kv"):
+        eng.forward(xin, t, fr, fr, fr, kc, vc, ck, cv)
+    img_k, img_v = eng.precompute_image_context(clip_fea.cuda())
+    assert img_k.shape == (cfg["num_layers"], 257, cfg["dim"])
+    eng.set_image_kv(img_k, img_v)
+    out = eng.forward(xin, t, fr, fr, fr, kc, vc, ck, cv)
+    torch.cuda.synchronize()
+    got = out.permute(1, 0, 2, 3).cpu()
+    e = rel_l2(got, fx["out"])
+    print(f"i2v model type forward: rel_l2 vs reference golden = {e:.3e}")
+    assert got.shape == fx["out"].shape and e < 2e-2
+    # detaching the image stream changes the result (the stream is really used)
+    eng.model_type = "t2v"
+    eng.set_image_kv(None, None)
+    kc.zero_(); vc.zero_()
+    out2 = eng.forward(xin, t, fr, fr, fr, kc, vc, ck, cv)
+    assert rel_l2(out2.permute(1, 0, 2, 3).cpu(), fx["out"]) > 1e-2
