@@ -181,6 +181,18 @@ int mmpl_i2v_cross_attn(const void* x, int Lq, int dim, const void* wq, const vo
                         const void* k_txt, const void* v_txt, int n_txt, const void* k_img, const void* v_img, int n_img,
                         const void* wo, const void* bo, void* out, void* workspace, size_t workspace_bytes, mmpl_stream_t stream);
 
+/* CLIP ViT-H/14 vision tower of Wan-I2V: VisionTransformer.forward(x, use_31_block=True) (wan/modules/clip.py:209-327) behind
+ * CLIPModel.visual (clip.py:527-542; the bicubic resize / normalisation / im2col are the caller's).
+ *   patches : dev [n_patch, pk] bf16, im2col of the normalised image in (c, ky, kx) order, K zero-padded to a multiple of 64
+ *   gw      : 5 dev pointers  patch_embedding.weight [dim, pk], cls_embedding [dim], pos_embedding [n_patch+1, dim], pre_norm.{weight,bias}
+ *   lw      : 12 per block    norm1.{weight,bias}, to_qkv.{weight [3*heads*128, dim], bias}, proj.{weight [dim, heads*128], bias},
+ *                             norm2.{weight,bias}, mlp.0.{weight,bias}, mlp.2.{weight,bias} -- heads padded from head_dim to 128
+ *   out     : dev [n_patch+1, dim] bf16, the tokens after n_blocks blocks (31 of the 32 for Wan-I2V) */
+size_t mmpl_clip_visual_workspace_bytes(int n_tok, int dim, int mlp_dim, int heads);
+int mmpl_clip_visual(const void* patches, int n_patch, int pk, int dim, int mlp_dim, int heads, int head_dim, int n_blocks,
+                     const void* const* gw, const void* const* lw, float eps, void* out, void* workspace, size_t workspace_bytes,
+                     mmpl_stream_t stream);
+
 /* Optional per-kernel-class hipEvent timing (bench.py's live roofline numbers; off by default, not thread-safe).
  * kinds: 0 gemm, 1 self-attention, 2 cross-attention, 3 layernorm, 4 qk-norm/rope/kv-write, 5 elementwise, 6 cfg+unipc,
  * 7 vae.  on = 0 off, 1 every kind, > 1: only the kinds in the bit mask (on >> 1) (e.g. 2 << 1 | ... ; bench.py times the

@@ -115,4 +115,82 @@ int mmpl_i2v_cross_attn(const void* x, int Lq, int dim, const void* wq, const vo
   return 0;
 }
 
+// ---------------------------------------------------------------- CLIP ViT-H/14 vision tower (Wan-I2V's image encoder)
+// VisionTransformer.forward(x, use_31_block=True) (MMPL_t2v/wan/modules/clip.py:209-327, called by CLIPModel.visual :527-542):
+// patch embedding (no bias: pre_norm) -> [cls; patches] + pos -> pre_norm -> n_blocks pre-norm blocks (clip.py:120-155: LayerNorm,
+// fused qkv, attention, proj, LayerNorm, Linear - GELU(erf) - Linear) -> the tokens themselves (no post_norm, no head).
+// The real tower has 16 heads of 80: every head is padded to 128 columns by the host when it packs the weights (zero rows in
+// to_qkv, zero columns in proj), so the DiT's 128-wide attention kernel serves it unchanged with softmax_scale = 1/sqrt(80).
+// patches: dev [n_patch, pk] = im2col of the normalised image, (c, ky, kx) order, K zero-padded to a multiple of 64.
+// gw: patch_embedding.weight [dim, pk], cls_embedding [dim], pos_embedding [n_patch + 1, dim], pre_norm.{weight, bias}.
+// lw: per block 12 pointers: norm1.{weight,bias}, to_qkv.{weight [3 H 128, dim], bias}, proj.{weight [dim, H 128], bias},
+//     norm2.{weight,bias}, mlp.0.{weight,bias}, mlp.2.{weight,bias}.
+size_t mmpl_clip_visual_workspace_bytes(int n_tok, int dim, int mlp_dim, int heads) {
+  const size_t wide = (size_t)(3 * heads * 128 > mlp_dim ? 3 * heads * 128 : mlp_dim);
+  return ((size_t)n_tok * dim * 2 + (size_t)n_tok * wide + (size_t)n_tok * heads * 128) * sizeof(bf16_t) + 4096;
+}
+
+int mmpl_clip_visual(const void* patches, int n_patch, int pk, int dim, int mlp_dim, int heads, int head_dim, int n_blocks,
+                     const void* const* gw, const void* const* lw, float eps, void* out, void* workspace, size_t workspace_bytes,
+                     mmpl_stream_t stream) {
+  if (!patches || !gw || !lw || !out || !workspace) return mmpl_set_error("mmpl_clip_visual", "null argument");
+  if (n_patch < 1 || pk % 64 || dim % 64 || mlp_dim % 64 || dim > 5120 || heads < 1 || head_dim < 1 || head_dim > 128 || n_blocks < 0)
+    return mmpl_set_error("mmpl_clip_visual", "unsupported dims");
+  const int n = n_patch + 1, hw = heads * 128;
+  if (workspace_bytes < mmpl_clip_visual_workspace_bytes(n, dim, mlp_dim, heads)) return mmpl_set_error("mmpl_clip_visual", "workspace too small");
+  for (int i = 0; i < 5; ++i)
+    if (!gw[i]) return mmpl_set_error("mmpl_clip_visual", "null weight pointer");
+  for (int i = 0; i < 12 * n_blocks; ++i)
+    if (!lw[i]) return mmpl_set_error("mmpl_clip_visual", "null weight pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const bf16_t* const* G = (const bf16_t* const*)gw;
+  const bf16_t* const* L = (const bf16_t* const*)lw;
+  const size_t wide = (size_t)(3 * hw > mlp_dim ? 3 * hw : mlp_dim);
+  auto al = [](size_t e) { return (e + 127) & ~(size_t)127; };
+  bf16_t* x = (bf16_t*)workspace;                 // [n, dim] the residual stream
+  bf16_t* hbuf = x + al((size_t)n * dim);         // [n, dim] LayerNorm output
+  bf16_t* big = hbuf + al((size_t)n * dim);       // [n, wide] qkv | mlp hidden
+  bf16_t* att = big + al((size_t)n * wide);       // [n, H 128]
+  // x = [cls; patches . W^T] + pos
+  I2V_TRY(hipMemcpyAsync(x, G[1], (size_t)dim * sizeof(bf16_t), hipMemcpyDeviceToDevice, s), "mmpl_clip_visual: cls");
+  {
+    GemmArgs g = {(const bf16_t*)patches, pk, G[0], pk, nullptr, x + dim, dim, n_patch, dim, pk, EPI_BIAS, nullptr, 0, nullptr, 0, 1, 1.0f, 0, 0, 0, 0, 0};
+    I2V_TRY(mmpl_launch_gemm(g, s), "mmpl_clip_visual: patch embedding");
+  }
+  add_kernel<<<blocks_for((size_t)n * dim), 256, 0, s>>>(x, G[2], (size_t)n * dim);
+  {
+    LnArgs l = {x, dim, hbuf, dim, n, dim, eps, nullptr, nullptr, 0, 1, G[3], G[4]};
+    I2V_TRY(mmpl_launch_layernorm(l, s), "mmpl_clip_visual: pre_norm");
+    I2V_TRY(hipMemcpyAsync(x, hbuf, (size_t)n * dim * sizeof(bf16_t), hipMemcpyDeviceToDevice, s), "mmpl_clip_visual: pre_norm copy");
+  }
+  for (int b = 0; b < n_blocks; ++b) {
+    const bf16_t* const* W = L + 12 * b;
+    LnArgs l1 = {x, dim, hbuf, dim, n, dim, eps, nullptr, nullptr, 0, 1, W[0], W[1]};
+    I2V_TRY(mmpl_launch_layernorm(l1, s), "mmpl_clip_visual: norm1");
+    I2V_TRY(linear(hbuf, dim, W[2], W[3], big, n, 3 * hw, s), "mmpl_clip_visual: to_qkv");
+    {
+      AttnArgs a = {};
+      a.q = big; a.ldq = 3 * hw; a.o = att; a.ldo = hw;
+      a.k_pages[0] = big + hw; a.v_pages[0] = big + 2 * hw; a.ldk = 3 * hw; a.ldv = 3 * hw;
+      a.n_pages = 1; a.page_rows = n; a.Lq = n; a.H = heads; a.scale = 1.0f / sqrtf((float)head_dim); a.cross = 1;
+      I2V_TRY(mmpl_launch_attention(a, s), "mmpl_clip_visual: attention");
+    }
+    {
+      GemmArgs g = {att, hw, W[4], hw, W[5], x, dim, n, dim, hw, EPI_RES, x, dim, nullptr, 0, 1, 1.0f, 0, 0, 0, 0, 0};
+      I2V_TRY(mmpl_launch_gemm(g, s), "mmpl_clip_visual: proj + residual");
+    }
+    LnArgs l2 = {x, dim, hbuf, dim, n, dim, eps, nullptr, nullptr, 0, 1, W[6], W[7]};
+    I2V_TRY(mmpl_launch_layernorm(l2, s), "mmpl_clip_visual: norm2");
+    I2V_TRY(linear(hbuf, dim, W[8], W[9], big, n, mlp_dim, s), "mmpl_clip_visual: mlp.0");
+    gelu_erf_kernel<<<blocks_for((size_t)n * mlp_dim), 256, 0, s>>>(big, (size_t)n * mlp_dim);
+    {
+      GemmArgs g = {big, mlp_dim, W[10], mlp_dim, W[11], x, dim, n, dim, mlp_dim, EPI_RES, x, dim, nullptr, 0, 1, 1.0f, 0, 0, 0, 0, 0};
+      I2V_TRY(mmpl_launch_gemm(g, s), "mmpl_clip_visual: mlp.2 + residual");
+    }
+  }
+  I2V_TRY(hipMemcpyAsync(out, x, (size_t)n * dim * sizeof(bf16_t), hipMemcpyDeviceToDevice, s), "mmpl_clip_visual: out");
+  I2V_TRY(hipGetLastError(), "mmpl_clip_visual");
+  return 0;
+}
+
 }  // extern "C"

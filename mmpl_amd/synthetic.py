@@ -85,6 +85,41 @@ def dit_i2v_state_dict(cfg: dict, seed: int = 0, clip_dim: int = 1280, dtype=tor
     return sd
 
 
+def clip_visual_state_dict(dim: int, num_heads: int, num_layers: int, image_size: int = 224, patch_size: int = 14, mlp_ratio: int = 4,
+                           seed: int = 0, dtype=torch.bfloat16, device="cpu"):
+    """state_dict of the reference's VisionTransformer(pool_type='token', pre_norm=True) minus ``head`` (a plain Parameter the
+    use_31_block path never touches): keys / shapes of MMPL_t2v/wan/modules/clip.py:253-286."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+
+    def rn(*shape, std):
+        return (torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * std).to(dtype)
+
+    def norm(name):
+        sd[name + ".weight"] = (1 + rn(dim, std=0.1).float()).to(dtype)
+        sd[name + ".bias"] = rn(dim, std=0.02)
+
+    def lin(name, out_f, in_f):
+        sd[name + ".weight"] = rn(out_f, in_f, std=in_f ** -0.5)
+        sd[name + ".bias"] = rn(out_f, std=0.02)
+    sd = OrderedDict()
+    n_patch = (image_size // patch_size) ** 2
+    sd["cls_embedding"] = rn(1, 1, dim, std=dim ** -0.5)
+    sd["pos_embedding"] = rn(1, n_patch + 1, dim, std=dim ** -0.5)
+    sd["patch_embedding.weight"] = rn(dim, 3, patch_size, patch_size, std=(3 * patch_size * patch_size) ** -0.5)
+    norm("pre_norm")
+    for i in range(num_layers):
+        p = f"transformer.{i}."
+        norm(p + "norm1")
+        lin(p + "attn.to_qkv", 3 * dim, dim)
+        lin(p + "attn.proj", dim, dim)
+        norm(p + "norm2")
+        lin(p + "mlp.0", int(dim * mlp_ratio), dim)
+        lin(p + "mlp.2", dim, int(dim * mlp_ratio))
+    norm("post_norm")
+    return sd
+
+
 def philox_normal(shape, seed: int, dtype=torch.bfloat16) -> torch.Tensor:
     """Build-owned counter-based N(0,1) generator (numpy Philox) so CPU container and GPU box regenerate
     identical inputs without the reference (RNG note)."""

@@ -90,3 +90,62 @@ def test_i2v_model_type_forward_vs_reference_golden():
     kc.zero_(); vc.zero_()
     out2 = eng.forward(xin, t, fr, fr, fr, kc, vc, ck, cv)
     assert rel_l2(out2.permute(1, 0, 2, 3).cpu(), fx["out"]) > 1e-2
+
+
+def test_clip_vision_tower_vs_reference_golden():
+    """CLIPVisionTower (mmpl_clip_visual) vs the reference's VisionTransformer.forward(x, use_31_block=True) on the reduced
+    config (head_dim 80, padded to 128 inside).  Stated tolerance: rel-L2 <= 2e-2."""
+    from mmpl_amd.i2v_clip import CLIPVisionTower
+    from mmpl_amd.synthetic import clip_visual_state_dict, philox_normal
+    fx = torch.load(f"{GOLDEN}/clip_visual_tiny.pt")
+    m = fx["meta"]
+    tower = CLIPVisionTower(m["image_size"], m["patch_size"], m["dim"], 4, m["num_heads"], m["num_layers"])
+    with pytest.raises(RuntimeError, match="weights not loaded"):
+        tower.forward_pixels(torch.zeros(1, 3, m["image_size"], m["image_size"]))
+    tower.load_state_dict(clip_visual_state_dict(m["dim"], m["num_heads"], m["num_layers"], m["image_size"], m["patch_size"], seed=m["weight_seed"]))
+    x = philox_normal([2, 3, m["image_size"], m["image_size"]], m["pixel_seed"])
+    out = tower.forward_pixels(x.cuda())
+    torch.cuda.synchronize()
+    e = rel_l2(out, fx["out"])
+    print(f"CLIP vision tower: rel_l2 vs reference golden = {e:.3e}")
+    assert out.shape == fx["out"].shape and e < 2e-2
+
+
+def test_clip_vision_tower_vit_h_dims_vs_oracle():
+    """ViT-H/14 geometry (224 px, 257 tokens, dim 1280, 16 heads of 80), 3 of the 32 layers (2 run); checker = the oracle on CPU.
+    Also the preprocessing of CLIPModel.visual (clip.py:529-538): a [-1, 1] video frame of another size goes in."""
+    from mmpl_amd.i2v_clip import CLIPVisionTower
+    from mmpl_amd.synthetic import clip_visual_state_dict, philox_normal
+    from oracle import clip_ref
+    sd = clip_visual_state_dict(1280, 16, 3, 224, 14, seed=3)
+    tower = CLIPVisionTower(224, 14, 1280, 4, 16, 3)
+    tower.load_state_dict(sd)
+    frame = (philox_normal([3, 1, 96, 160], 61).float() * 0.4).clamp(-1, 1)          # [3, T=1, H, W]
+    out = tower.visual([frame])
+    torch.cuda.synchronize()
+    px = tower.preprocess([frame]).to(torch.bfloat16)
+    ref = clip_ref.clip_visual(sd, px, 16, 3, 14)
+    e = rel_l2(out, ref)
+    print(f"CLIP ViT-H dims: rel_l2 vs oracle = {e:.3e}")
+    assert out.shape == (1, 257, 1280) and e < 2e-2
+
+
+def test_image_to_dit_chain_runs():
+    """image frame -> CLIPVisionTower.visual -> DitEngine.precompute_image_context -> i2v forward: the pieces fit (shapes, dtypes,
+    finite output); each piece's numbers are checked by the tests above."""
+    from mmpl_amd.dit import DitEngine
+    from mmpl_amd.i2v_clip import CLIPVisionTower
+    from mmpl_amd.synthetic import WAN_CONFIGS, clip_visual_state_dict, dit_i2v_state_dict, philox_normal
+    tower = CLIPVisionTower(224, 14, 1280, 4, 16, 2)
+    tower.load_state_dict(clip_visual_state_dict(1280, 16, 2, 224, 14, seed=4))
+    clip_fea = tower.visual([(philox_normal([3, 1, 64, 64], 71).float() * 0.4).clamp(-1, 1)])[0]
+    cfg = dict(WAN_CONFIGS["tiny"], model_type="i2v")
+    eng = DitEngine(cfg, 16, 16, max_frames=2)
+    eng.load_state_dict(dit_i2v_state_dict(cfg, seed=2))
+    eng.set_image_kv(*eng.precompute_image_context(clip_fea))
+    ck, cv = eng.precompute_context(philox_normal([20, cfg["text_dim"]], 72).cuda())
+    kc, vc = eng.new_kv_cache(2)
+    x = philox_normal([2, 36, 16, 16], 73).cuda()
+    out = eng.forward(x, torch.full([2], 500.0, dtype=torch.float32, device="cuda"), [0, 1], [0, 1], [0, 1], kc, vc, ck, cv)
+    torch.cuda.synchronize()
+    assert out.shape == (2, 16, 16, 16) and torch.isfinite(out.float()).all() and out.float().abs().max() > 0
