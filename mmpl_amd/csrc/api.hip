@@ -3,6 +3,7 @@
 // no allocation, so it is hipGraph-capturable per (stage, pass) shape.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -322,6 +323,8 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
   const float scale = 1.0f / sqrtf(128.0f);
   const int self_variant = mmpl_attention_self_variant();
   const bool prescale_q = self_variant == ATTN_W64;         // fold scale * log2(e) into q before it is rounded (kernels.h)
+  static const bool cross_w64_env = getenv("MMPL_CROSS_W64") != nullptr;
+  const bool cross_w64 = cross_w64_env && prescale_q;       // text / image cross-attention on the 64-rows-per-wave kernel too
   const size_t layer_stride = (size_t)n_slots * S * d;
   for (int l = 0; l < c.num_layers; ++l) {
     const bf16_t* em = w.emod + (size_t)l * nF * 6 * d;  // [nF][6][d]
@@ -389,13 +392,14 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
     TRY(gemm(w.xn, d, h->Lw(l, L_CQ_W), d, h->Lw(l, L_CQ_B), w.big, d, Lq, d, d, EPI_BIAS, nullptr, 0, nullptr, 0, 1, s));
     {
       ProfScope ps(K_QKNORM, 0, s);
-      HIP_TRY(mmpl_launch_rmsnorm(w.big, d, h->Lw(l, L_CNQ), Lq, d, c.eps, s), "cross q norm");
+      HIP_TRY(mmpl_launch_rmsnorm(w.big, d, h->Lw(l, L_CNQ), Lq, d, c.eps, s, cross_w64 ? scale * 1.4426950408889634f : 0.f), "cross q norm");
     }
     {
       AttnArgs a = {};
       a.q = w.big; a.ldq = d; a.o = w.attn; a.ldo = d; a.ldk = d; a.ldv = d; a.page_rows = T; a.Lq = Lq; a.H = H; a.scale = scale;
       a.n_pages = 1;
       a.cross = 1;
+      if (cross_w64) { a.variant = ATTN_W64; a.q_prescaled = true; }
       a.k_pages[0] = (const bf16_t*)cross_k + (size_t)l * T * d;
       a.v_pages[0] = (const bf16_t*)cross_v + (size_t)l * T * d;
       ProfScope ps(K_ATTN_CROSS, 4.0 * Lq * (double)T * d, s);

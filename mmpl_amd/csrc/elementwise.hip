@@ -293,9 +293,10 @@ hipError_t mmpl_launch_qknorm(const QkNormArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t mmpl_launch_rmsnorm(bf16_t* x, int ldx, const bf16_t* w, int rows, int d, float eps, hipStream_t s) {
+hipError_t mmpl_launch_rmsnorm(bf16_t* x, int ldx, const bf16_t* w, int rows, int d, float eps, hipStream_t s, float out_scale) {
   QkNormArgs a = {};
   a.q = x; a.ldq = ldx; a.wq = w; a.rows = rows; a.d = d; a.eps = eps; a.rope = 0; a.rows_per_frame = rows > 0 ? rows : 1;
+  a.q_scale = out_scale;
   a.grid_w = 1;
   return mmpl_launch_qknorm(a, s);
 }

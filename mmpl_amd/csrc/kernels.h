@@ -93,7 +93,8 @@ struct QkNormArgs {
 hipError_t mmpl_launch_qknorm(const QkNormArgs& a, hipStream_t s);
 
 // rmsnorm of a plain [rows, d] matrix in place (context K)
-hipError_t mmpl_launch_rmsnorm(bf16_t* x, int ldx, const bf16_t* w, int rows, int d, float eps, hipStream_t s);
+// out_scale != 0: the normalised row is multiplied by it before its (single) rounding (a q that feeds ATTN_W64: scale * log2 e)
+hipError_t mmpl_launch_rmsnorm(bf16_t* x, int ldx, const bf16_t* w, int rows, int d, float eps, hipStream_t s, float out_scale = 0.f);
 
 // emod[l][f][k][:] = bf16(mod[l*mod_layer_stride + k*d + :] + e[f*e_frame_stride + (bcast ? : : k*d + :)])   (k < nmod)
 hipError_t mmpl_launch_modulation(const bf16_t* mod, size_t mod_layer_stride, const bf16_t* e, int e_frame_stride, int bcast,

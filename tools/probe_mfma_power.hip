@@ -1,0 +1,72 @@
+// HW probe (dev): sustained rate of back-to-back MFMAs on random (non-zero) data, one wave per SIMD, by instruction shape --
+// v_mfma_f32_32x32x16_bf16 (16 accumulator registers read + written per 32768 FLOP) vs v_mfma_f32_16x16x32_bf16 (4 per 16384).
+// The chip is power-limited under dense MFMA streams, so the shape that moves fewer register-file bytes per FLOP may clock higher.
+//   hipcc --offload-arch=gfx950 -O3 -o tools/build/probe_mfma_power tools/probe_mfma_power.hip && tools/build/probe_mfma_power
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int SHAPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void mfma_loop(const bf16x8* in, float* out, int iters) {
+  const int lane = threadIdx.x & 63;
+  bf16x8 a[4], b[4];
+  for (int i = 0; i < 4; ++i) { a[i] = in[(lane + 64 * i) & 1023]; b[i] = in[(lane * 7 + 64 * i + 13) & 1023]; }
+  float r = 0.f;
+  if constexpr (SHAPE == 32) {
+    f32x16 acc[8];
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(i + u) & 3], b[i & 3], acc[i], 0, 0, 0);
+    }
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 16; ++j) r += acc[i][j];
+  } else {
+    f32x4 acc[32];
+    for (int i = 0; i < 32; ++i) for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 32; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(i + u) & 3], b[(i >> 2) & 3], acc[i], 0, 0, 0);
+    }
+    for (int i = 0; i < 32; ++i) for (int j = 0; j < 4; ++j) r += acc[i][j];
+  }
+  if (r == 12345.678f) out[0] = r;
+  if (lane == 0 && blockIdx.x == 0) out[1 + (threadIdx.x >> 6)] = r;
+}
+
+template <int SHAPE> void run(const bf16x8* in, float* out, const char* name) {
+  const int blocks = 256 * 4, iters = 4000;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0);
+    for (int k = 0; k < 5; ++k) hipLaunchKernelGGL(mfma_loop<SHAPE>, dim3(blocks), dim3(256), 0, 0, in, out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double flops = 5.0 * blocks * 4.0 * iters * 32.0 * 32768.0;      // both shapes: 32 x 32768 = 64 x 16384 FLOP per wave per iteration
+    printf("%s: %.2f ms  %.0f TFLOP/s\n", name, ms, flops / ms / 1e9);
+  }
+}
+
+int main() {
+  std::vector<uint16_t> h(1024 * 8);
+  uint32_t s = 12345;
+  for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (uint16_t)(0x3c00 + ((s >> 9) & 0x3ff) + ((s >> 31) << 15)); }   // +-[0.0078, 0.03]: full mantissa activity
+  bf16x8* in; float* out;
+  hipMalloc(&in, h.size() * 2); hipMalloc(&out, 64);
+  hipMemcpy(in, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+  run<32>(in, out, "v_mfma_f32_32x32x16_bf16");
+  run<16>(in, out, "v_mfma_f32_16x16x32_bf16");
+  run<32>(in, out, "v_mfma_f32_32x32x16_bf16");
+  run<16>(in, out, "v_mfma_f32_16x16x32_bf16");
+  return 0;
+}
