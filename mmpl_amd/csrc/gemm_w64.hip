@@ -116,18 +116,31 @@ struct GCtx {
   MMPL_DEV void barrier() { if constexpr (GEMM_ABL & 8) return; asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory"); }
 };
 
-// One k stage: MFMAs on register buffer P, the next stage's fragments into buffer P ^ 1.
+// One k stage: MFMAs on register buffer P, the next stage's fragments into buffer P ^ 1.  Gap placement (dev sweep: -DGEMM_BAR=..):
+#ifndef GEMM_BAR
+#define GEMM_BAR 8        // gap of the barrier
+#endif
+#ifndef GEMM_LDS0
+#define GEMM_LDS0 (GEMM_BAR + 2)   // first fragment read (16 reads, one per gap)
+#endif
+#ifndef GEMM_DMA0
+#define GEMM_DMA0 (GEMM_BAR + 2)   // first DMA piece
+#endif
+#ifndef GEMM_DMAS
+#define GEMM_DMAS 3       // gaps between DMA pieces
+#endif
 template <int P, bool RES> MMPL_DEV void gemm_stage(GCtx& k) {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // buffer P (read during the previous stage's gaps 10..25)
+  static_assert(GEMM_LDS0 > GEMM_BAR + 1 && GEMM_LDS0 + 16 <= 32 && GEMM_DMA0 > GEMM_BAR && GEMM_DMA0 + 7 * GEMM_DMAS < 32, "placement");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // buffer P (read during the previous stage)
   sfor<32>([&k](auto gi) {
     constexpr int g = decltype(gi)::value;
     k.template mfma<P, g>();
-    if constexpr (g == 8) k.barrier();
-    if constexpr (g == 9) k.read_addr();
-    if constexpr (g >= 10 && g < 26) k.template lds<P ^ 1, g - 10>();
-    if constexpr (g >= 10 && (g - 10) % 3 == 0) {
-      if constexpr (RES) k.template dma_res<(g - 10) / 3>();
-      else k.template dma<(g - 10) / 3>();
+    if constexpr (g == GEMM_BAR) k.barrier();
+    if constexpr (g == GEMM_BAR + 1) k.read_addr();
+    if constexpr (g >= GEMM_LDS0 && g < GEMM_LDS0 + 16) k.template lds<P ^ 1, g - GEMM_LDS0>();
+    if constexpr (g >= GEMM_DMA0 && (g - GEMM_DMA0) % GEMM_DMAS == 0 && (g - GEMM_DMA0) / GEMM_DMAS < 8) {
+      if constexpr (RES) k.template dma_res<(g - GEMM_DMA0) / GEMM_DMAS>();
+      else k.template dma<(g - GEMM_DMA0) / GEMM_DMAS>();
     }
   });
   k.dma_advance();
