@@ -352,9 +352,14 @@ MMPL_DEV void glds16s(const void* base, uint32_t voff, char* lds) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(dst) : "memory");
 }
 
+#ifndef GEMM6_TIMING
+#define GEMM6_TIMING 0      // dev: 1 = every wave leaves { prologue, k loop, epilogue } shader cycles over the output (tools/bench_kernels.py gemmphases)
+#endif
 template <int EPI>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_v6_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  [[maybe_unused]] unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+  if constexpr (GEMM6_TIMING) tk0 = __builtin_readcyclecounter();
   const int tiles_m = (g.M + BM3 - 1) / BM3, tiles_n = (g.N + BN3 - 1) / BN3;
   const int nwg = tiles_m * tiles_n;
   int bid = blockIdx.x;
@@ -410,6 +415,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   __builtin_amdgcn_s_barrier();
   if (grp == 1) __builtin_amdgcn_s_barrier();          // group B runs half a tile late
+  if constexpr (GEMM6_TIMING) tk1 = __builtin_readcyclecounter();
 
   for (int t = 0; t < nt; ++t) {
     // =========================== R_t
@@ -453,8 +459,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __builtin_amdgcn_s_barrier();
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
+  if constexpr (GEMM6_TIMING) tk2 = __builtin_readcyclecounter();
   gemm_epilogue<EPI>(g, acc[0], m0 + 128 * wm, n0 + 64 * wn, frow, fchunk);
   gemm_epilogue<EPI>(g, acc[1], m0 + 128 * wm + 64, n0 + 64 * wn, frow, fchunk);
+  if constexpr (GEMM6_TIMING) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tk3 = __builtin_readcyclecounter();
+    __syncthreads();
+    if (lane == 0 && (wave & 1) == 0) {                      // 4 of the 8 waves: the layout tools/bench_kernels.py gemmphases reads
+      float* tp = reinterpret_cast<float*>(g.C) + (blockIdx.x * 4 + (wave >> 1)) * 4;
+      tp[0] = (float)(tk1 - tk0);
+      tp[1] = (float)(tk2 - tk1);
+      tp[2] = (float)(tk3 - tk2);
+      tp[3] = (float)(2 * nt);                                // in 32-wide k stages, like gemm_w64
+    }
+  }
 }
 
 template <int EPI>
