@@ -352,6 +352,84 @@ MMPL_DEV void glds16s(const void* base, uint32_t voff, char* lds) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(dst) : "memory");
 }
 
+// v6 epilogue, LDS-staged.  The MFMA leaves each lane with one token row and 4 consecutive output columns per fragment: stored
+// directly that is 8 bytes per lane into 64 different rows per instruction.  Instead: bias, the Linear's bf16 rounding and the
+// activation happen on the MFMA side, the wave's 128 x 64 sub-tile goes to its 16 KiB of the (now idle) LDS ring as bf16
+// (16-byte chunk c of row r at r*128 + 16*(c ^ (r & 7))), and is read back row-major: a lane owns 8 consecutive columns of
+// a row -> 16-byte residual / gate loads and stores, 128 contiguous bytes per row.  Every residual load of the sub-tile is
+// issued before the first store (the residual usually IS the output buffer) and all of them are in flight at once.
+template <int EPI>
+MMPL_DEV void gemm_epilogue_staged(const GemmArgs& g, const f32x4 (&acc)[2][4][4], char* stg, int mw, int nw, int lane) {
+  constexpr bool HAS_RES = EPI == EPI_GATE_RES || EPI == EPI_RES;
+  const int frow = lane & 15, fchunk = lane >> 4;
+  const int erow = lane >> 3, ec = lane & 7, n = nw + 8 * ec;      // row-major side: step u -> row 8 u + erow, columns 8 ec .. + 7
+  const bool n_ok = n < g.N;                                        // N % 8 == 0 on this path (launcher)
+  uint4 res8[16];
+  if (HAS_RES) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int m = mw + 8 * u + erow;
+      res8[u] = (n_ok && m < g.M) ? *reinterpret_cast<const uint4*>(g.res + (size_t)m * g.ldres + n) : uint4{0u, 0u, 0u, 0u};
+    }
+  }
+  uint2 bias4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int nb = nw + 16 * j + 4 * fchunk;
+    bias4[j] = (g.bias && nb < g.N) ? *reinterpret_cast<const uint2*>(g.bias + nb) : uint2{0u, 0u};
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 64 * h + 16 * i + frow;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float b[4] = {__uint_as_float(bias4[j].x << 16), __uint_as_float(bias4[j].x & 0xffff0000u),
+                            __uint_as_float(bias4[j].y << 16), __uint_as_float(bias4[j].y & 0xffff0000u)};
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = rbf(acc[h][i][j][r] + b[r]);                       // Linear output rounds to bf16
+          if (EPI == EPI_BIAS_GELU) v[r] = gelu_tanh(v[r]);
+          if (EPI == EPI_BIAS_SILU) v[r] = silu(v[r]);
+        }
+        const int c = 2 * j + (fchunk >> 1);                        // 16-byte chunk of the row; (fchunk & 1) picks its half
+        *reinterpret_cast<uint2*>(stg + row * 128 + ((c ^ (row & 7)) << 4) + 8 * (fchunk & 1)) = uint2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+      }
+    }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int row = 8 * u + erow, m = mw + row;
+    const uint4 yv = *reinterpret_cast<const uint4*>(stg + row * 128 + ((ec ^ (row & 7)) << 4));
+    if (m >= g.M || !n_ok) continue;
+    uint4 ov = yv;
+    if (HAS_RES) {
+      uint4 ev = uint4{0u, 0u, 0u, 0u};
+      if (EPI == EPI_GATE_RES) ev = *reinterpret_cast<const uint4*>(g.gate + (size_t)(m / g.rows_per_frame) * g.gate_frame_stride + n);
+      const uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w}, xw[4] = {res8[u].x, res8[u].y, res8[u].z, res8[u].w}, ew[4] = {ev.x, ev.y, ev.z, ev.w};
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float y = __uint_as_float((e & 1) ? (yw[e >> 1] & 0xffff0000u) : (yw[e >> 1] << 16));
+        const float x = __uint_as_float((e & 1) ? (xw[e >> 1] & 0xffff0000u) : (xw[e >> 1] << 16));
+        if (EPI == EPI_GATE_RES) y = rbf(y * __uint_as_float((e & 1) ? (ew[e >> 1] & 0xffff0000u) : (ew[e >> 1] << 16)));   // y * e rounds
+        v[e] = x + y;                                               // x + (.) rounds at the pack
+      }
+      ov.x = pack2bf(v[0], v[1]); ov.y = pack2bf(v[2], v[3]); ov.z = pack2bf(v[4], v[5]); ov.w = pack2bf(v[6], v[7]);
+    }
+    if (EPI == EPI_BIAS_VPAGES && n >= g.v_col0) {
+      const int fr = m / g.rows_per_frame;
+      *reinterpret_cast<uint4*>(g.v_dst[fr] + (size_t)(m - fr * g.rows_per_frame) * g.v_ld + (n - g.v_col0)) = ov;
+    } else {
+      *reinterpret_cast<uint4*>(g.C + (size_t)m * g.ldc + n) = ov;
+    }
+  }
+}
+
 #ifndef GEMM6_TIMING
 #define GEMM6_TIMING 0      // dev: 1 = every wave leaves { prologue, k loop, epilogue } shader cycles over the output (tools/bench_kernels.py gemmphases)
 #endif
@@ -460,8 +538,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
   if constexpr (GEMM6_TIMING) tk2 = __builtin_readcyclecounter();
-  gemm_epilogue<EPI>(g, acc[0], m0 + 128 * wm, n0 + 64 * wn, frow, fchunk);
-  gemm_epilogue<EPI>(g, acc[1], m0 + 128 * wm + 64, n0 + 64 * wn, frow, fchunk);
+  if (EPI != EPI_F32_SCALE && g.staged_epilogue) {
+    gemm_epilogue_staged<EPI>(g, acc, smem + wave * (128 * 128), m0 + 128 * wm, n0 + 64 * wn, lane);
+  } else {
+    gemm_epilogue<EPI>(g, acc[0], m0 + 128 * wm, n0 + 64 * wn, frow, fchunk);
+    gemm_epilogue<EPI>(g, acc[1], m0 + 128 * wm + 64, n0 + 64 * wn, frow, fchunk);
+  }
   if constexpr (GEMM6_TIMING) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     tk3 = __builtin_readcyclecounter();
@@ -483,6 +565,11 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
   const int tiles = ((g.M + BM3 - 1) / BM3) * ((g.N + BN3 - 1) / BN3);
   GemmArgs g2 = g;
   g2.group = 4;
+  // the 16-byte epilogue needs 8-element alignment of everything it touches; otherwise the direct 8-byte one
+  static const bool env_direct = getenv("MMPL_GEMM_DIRECT_EPILOGUE") != nullptr;
+  g2.staged_epilogue = !env_direct && g.N % 8 == 0 && g.ldc % 8 == 0 && (g.epi != EPI_GATE_RES || g.gate_frame_stride % 8 == 0) &&
+                       ((g.epi != EPI_GATE_RES && g.epi != EPI_RES) || g.ldres % 8 == 0) &&
+                       (g.epi != EPI_BIAS_VPAGES || (g.v_col0 % 8 == 0 && g.v_ld % 8 == 0));
   hipLaunchKernelGGL(gemm_bf16_v6_kernel<EPI>, dim3(tiles), dim3(512), smem, s, g2);
   return hipGetLastError();
 }

@@ -28,6 +28,7 @@ struct GemmArgs {
   long sA, sW, sC;
   // EPI_BIAS_VPAGES: row m, column n >= v_col0 is written to v_dst[m / rows_per_frame] + (m % rows_per_frame) * v_ld + n - v_col0
   bf16_t* v_dst[8]; int v_col0, v_ld;
+  int staged_epilogue;           // v6: LDS-staged 16-byte epilogue (set by the launcher when every pointer / stride allows it)
 };
 hipError_t mmpl_launch_gemm(const GemmArgs& g, hipStream_t s);
 bool mmpl_gemm_w64_accepts(const GemmArgs& g);                      // gemm_w64.hip: the one-wave-per-SIMD kernel for the large linears
