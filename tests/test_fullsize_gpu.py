@@ -164,3 +164,36 @@ def test_t5_production_dims_two_layers_vs_cpu_oracle():
     e = rel_l2(out[0, :91], want[0, :91])
     print(f"umT5 xxl dims, 2 layers: rel_l2(HIP, CPU oracle) = {e:.3e}")
     assert e < 2e-2 and out[0, 91:].abs().sum().item() == 0
+
+
+def test_i2v_model_type_production_dims():
+    """WanModel(model_type='i2v') geometry at real dims: 1.3B width (dim 1536, 12 heads), 480p frames (1560 ragged-tile tokens),
+    in_dim 36, 257 CLIP tokens of 1280 through img_emb, 4 layers, 3 frames that write and see each other; checker = the oracle
+    code on the device (as above).  The tiny-size forward is pinned to the reference itself in tests/test_i2v_clip_gpu.py."""
+    from mmpl_amd.dit import DitEngine
+    from mmpl_amd.synthetic import WAN_CONFIGS, dit_i2v_state_dict
+    from oracle import wan_dit_ref as W
+    dev = "cuda:0"
+    cfg = dict(WAN_CONFIGS["1.3B"], num_layers=4, model_type="i2v")
+    sd = dit_i2v_state_dict(cfg, seed=31, device=dev)
+    eng = DitEngine(cfg, 60, 104, dev, max_frames=3)
+    eng.load_state_dict(sd)
+    ocfg = W.DitCfg(**{k: v for k, v in dict(cfg, in_dim=36).items() if k != "model_type"})
+    g = torch.Generator(device=dev).manual_seed(32)
+    ctx = torch.randn(512, cfg["text_dim"], generator=g, device=dev).bfloat16()
+    ctx[77:] = 0
+    clip_fea = torch.randn(257, 1280, generator=g, device=dev).bfloat16()
+    x = torch.randn(3, 36, 60, 104, generator=g, device=dev).bfloat16()
+    t = torch.full([3], 611.0, dtype=torch.float32, device=dev)
+    fr = [0, 1, 2]
+    kc, vc = eng.new_kv_cache(3)
+    ck, cv = eng.precompute_context(ctx)
+    eng.set_image_kv(*eng.precompute_image_context(clip_fea))
+    y = eng.forward(x, t, fr, fr, fr, kc, vc, ck, cv)
+    okv = [{n: u.to(dev) for n, u in d.items()} for d in W.new_kv_cache(ocfg, 3, eng.S)]
+    yo = W.dit_forward(sd, ocfg, x.permute(1, 0, 2, 3), t.view(1, -1), ctx, okv, [None] * cfg["num_layers"], fr, fr, fr, attn_fn=_grouped_sdpa,
+                       clip_fea=clip_fea).permute(1, 0, 2, 3)
+    torch.cuda.synchronize()
+    e = rel_l2(y, yo)
+    print(f"i2v model type, dim 1536 / 480p / 4 layers: rel_l2(HIP, oracle on device) = {e:.3e}")
+    assert torch.isfinite(y.float()).all() and e < TOL

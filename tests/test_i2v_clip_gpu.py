@@ -149,3 +149,21 @@ def test_image_to_dit_chain_runs():
     out = eng.forward(x, torch.full([2], 500.0, dtype=torch.float32, device="cuda"), [0, 1], [0, 1], [0, 1], kc, vc, ck, cv)
     torch.cuda.synchronize()
     assert out.shape == (2, 16, 16, 16) and torch.isfinite(out.float()).all() and out.float().abs().max() > 0
+
+
+def test_clip_vision_tower_all_31_blocks_vs_oracle():
+    """The whole ViT-H/14 tower as Wan-I2V runs it: 32 layers built, 31 run, 257 tokens, dim 1280; checker = the CPU oracle
+    (oracle/clip_ref.py).  Error accumulates over 31 residual blocks: stated tolerance 2e-2."""
+    from mmpl_amd.i2v_clip import CLIPVisionTower
+    from mmpl_amd.synthetic import clip_visual_state_dict, philox_normal
+    from oracle import clip_ref
+    sd = clip_visual_state_dict(1280, 16, 32, 224, 14, seed=8)
+    tower = CLIPVisionTower()
+    tower.load_state_dict(sd)
+    px = (philox_normal([1, 3, 224, 224], 81).float() * 1.2).to(torch.bfloat16)
+    out = tower.forward_pixels(px.cuda())
+    torch.cuda.synchronize()
+    ref = clip_ref.clip_visual(sd, px, 16, 32, 14)
+    e = rel_l2(out, ref)
+    print(f"CLIP ViT-H/14, 31 blocks: rel_l2 vs oracle = {e:.3e}")
+    assert out.shape == (1, 257, 1280) and torch.isfinite(out.float()).all() and e < 2e-2
