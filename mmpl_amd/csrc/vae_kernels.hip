@@ -12,13 +12,17 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BM = 128, BK = 32;        // the N tile is a template parameter of conv_igemm_kernel
 constexpr int TILE_BYTES = BM * BK * 2;  // 8 KiB
 
 // swizzled byte offset of 16-B chunk c (0..3) of row r inside a [128][32] bf16 tile: chunk' = c ^ ((-(r>>2)) & 3)
 MMPL_DEV int swz(int r, int c) { return r * 64 + ((c ^ ((0 - (r >> 2)) & 3)) << 4); }
 
+// NF = 16-column fragments per wave along N: 4 -> a 128-wide N tile, 3 -> 96-wide (the C = 96 layers of the decoder's full-resolution
+// stage, 40 % of a decode's conv time, would otherwise multiply 32 padding columns per tile)
+template <int NF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void conv_igemm_kernel(ConvArgs g) {
+  constexpr int BN = 32 * NF;
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
   char* As = smem;
   char* Ws = smem + 2 * TILE_BYTES;
@@ -66,33 +70,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
   store(0);
   __syncthreads();
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][NF];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int frow = lane & 15, fchunk = lane >> 4;
-  int a_off[4], w_off[4];
+  int a_off[4], w_off[NF];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    a_off[i] = swz(64 * wm + 16 * i + frow, fchunk);
-    w_off[i] = swz(64 * wn + 16 * i + frow, fchunk);
-  }
+  for (int i = 0; i < 4; ++i) a_off[i] = swz(64 * wm + 16 * i + frow, fchunk);
+#pragma unroll
+  for (int j = 0; j < NF; ++j) w_off[j] = swz(16 * NF * wn + 16 * j + frow, fchunk);
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
     if (t + 1 < nt) load(t + 1);
     const char* Ac = As + cur * TILE_BYTES;
     const char* Wc = Ws + cur * TILE_BYTES;
-    bf16x8 af[4], wf[4];
+    bf16x8 af[4], wf[NF];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      af[i] = *reinterpret_cast<const bf16x8*>(Ac + a_off[i]);
-      wf[i] = *reinterpret_cast<const bf16x8*>(Wc + w_off[i]);
-    }
+    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Ac + a_off[i]);
+#pragma unroll
+    for (int j = 0; j < NF; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(Wc + w_off[j]);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
     if (t + 1 < nt) store(cur ^ 1);
     __syncthreads();
   }
@@ -104,8 +106,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     const int x = m % g.Wo, y = (m / g.Wo) % g.Ho, t = m / (g.Wo * g.Ho);
     const size_t dpix = ((size_t)(t + g.dt0) * g.Hd + (y + g.dy0)) * g.Wd + (x + g.dx0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + 64 * wn + 16 * j + 4 * fchunk;
+    for (int j = 0; j < NF; ++j) {
+      const int n = n0 + 16 * NF * wn + 16 * j + 4 * fchunk;
       if (n >= g.N) continue;
       float v[4];
       const u32x2 bb = *reinterpret_cast<const u32x2*>(g.bias + n);
@@ -123,20 +125,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
   }
 }
 
-// ---- RMS_norm (F.normalize over C * sqrt(C) * gamma, vae.py:51-54) [+ SiLU] -> padded destination.  One wave per
-// pixel group: C <= 768 channels = <= 96 chunks of 8; each lane handles up to 2 chunks.
+// ---- RMS_norm (F.normalize over C * sqrt(C) * gamma, vae.py:51-54) [+ SiLU] -> padded destination.  LG lanes per pixel, 16 bytes
+// (8 channels) per lane per pass: LG = 16 for C <= 128, 32 for C <= 256, else the whole wave with up to two passes (C <= 1024) --
+// so a wave normalises 4 / 2 / 1 pixels and every lane moves data (with one pixel per wave the C = 96 layers of the decoder's
+// full-resolution stage kept 12 of 64 lanes busy and the kernel ran at a quarter of the HBM rate: 27 % of a decode).
+template <int LG>
 __global__ __launch_bounds__(256) void norm_act_pad_kernel(NormArgs a) {
-  const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (pix >= a.npix) return;
-  const int lane = threadIdx.x & 63;
+  constexpr int PPW = 64 / LG, NIT = LG == 64 ? 2 : 1;
+  const int lane = threadIdx.x & 63, sub = lane % LG;
+  const long pix = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW + lane / LG;
+  const bool live = pix < a.npix;
   const int nchunk = a.C >> 3;
-  const bf16_t* sp = a.src + (size_t)pix * a.C;
-  float v[2][8];
+  const bf16_t* sp = a.src + (size_t)(live ? pix : 0) * a.C;
+  float v[NIT][8];
   float sq = 0.f;
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int ch = lane + 64 * it;
-    if (ch < nchunk) {
+  for (int it = 0; it < NIT; ++it) {
+    const int ch = sub + LG * it;
+    if (live && ch < nchunk) {
       const u32x4 u = *reinterpret_cast<const u32x4*>(sp + ch * 8);
       v[it][0] = bf2f(u.x & 0xffff); v[it][1] = bf2f(u.x >> 16); v[it][2] = bf2f(u.y & 0xffff); v[it][3] = bf2f(u.y >> 16);
       v[it][4] = bf2f(u.z & 0xffff); v[it][5] = bf2f(u.z >> 16); v[it][6] = bf2f(u.w & 0xffff); v[it][7] = bf2f(u.w >> 16);
@@ -144,13 +150,18 @@ __global__ __launch_bounds__(256) void norm_act_pad_kernel(NormArgs a) {
       for (int j = 0; j < 8; ++j) sq += v[it][j] * v[it][j];
     }
   }
+  float denom = 1.f;
+  if (a.gamma) {
+#pragma unroll
+    for (int o = LG / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);          // sum over the pixel's LG lanes
+    denom = fmaxf(rbf(sqrtf(sq)), 1e-12f);                                       // torch.norm output is a bf16 tensor, clamp_min(eps)
+  }
+  if (!live) return;
   const int x = (int)(pix % a.W), y = (int)((pix / a.W) % a.H), t = (int)(pix / ((long)a.W * a.H));
   bf16_t* dp = a.dst + (((size_t)(t + a.dt0) * a.Hd + (y + a.dy0)) * a.Wd + (x + a.dx0)) * a.ldd;
-  float denom = 1.f;
-  if (a.gamma) denom = fmaxf(rbf(sqrtf(wave_sum(sq))), 1e-12f);   // torch.norm output is a bf16 tensor, clamp_min(eps)
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int ch = lane + 64 * it;
+  for (int it = 0; it < NIT; ++it) {
+    const int ch = sub + LG * it;
     if (ch >= nchunk) continue;
     float o[8];
     if (a.gamma) {
@@ -316,14 +327,21 @@ inline int grid_for(long n, int block = 256) {
 hipError_t vae_launch_conv(const ConvArgs& g, hipStream_t s) {
   if (g.M <= 0) return hipSuccess;
   if (g.Cin % 32 || g.N % 4 || g.ntaps < 1 || g.ntaps > 27) return hipErrorInvalidValue;
-  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-  hipLaunchKernelGGL(conv_igemm_kernel, dim3(tiles), dim3(256), 0, s, g);
+  if (g.N % 96 == 0 && g.N % 128 != 0) {                     // 96, 288, ...: no padding columns with the 96-wide tile
+    const int tiles = ((g.M + BM - 1) / BM) * (g.N / 96);
+    hipLaunchKernelGGL(conv_igemm_kernel<3>, dim3(tiles), dim3(256), 0, s, g);
+  } else {
+    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + 127) / 128);
+    hipLaunchKernelGGL(conv_igemm_kernel<4>, dim3(tiles), dim3(256), 0, s, g);
+  }
   return hipGetLastError();
 }
 hipError_t vae_launch_norm(const NormArgs& a, hipStream_t s) {
   if (a.npix <= 0) return hipSuccess;
   if (a.C % 8 || a.C > 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(norm_act_pad_kernel, dim3((unsigned)((a.npix + 3) / 4)), dim3(256), 0, s, a);
+  if (a.C <= 128) hipLaunchKernelGGL(norm_act_pad_kernel<16>, dim3((unsigned)((a.npix + 15) / 16)), dim3(256), 0, s, a);
+  else if (a.C <= 256) hipLaunchKernelGGL(norm_act_pad_kernel<32>, dim3((unsigned)((a.npix + 7) / 8)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(norm_act_pad_kernel<64>, dim3((unsigned)((a.npix + 3) / 4)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 hipError_t vae_launch_upsample(const UpArgs& a, hipStream_t s) {
