@@ -534,9 +534,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           acc[i >> 2][i & 3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[i >> 2][i & 3][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t+1 landed before anyone reads it
-    __builtin_amdgcn_s_barrier();
+    // group A's barrier here pairs with group B's after R_t: it also tells A that B's last fragment reads of the ring are done.
+    // B's own barrier after its LAST multiply would only pair with an extra one in A, and nothing needs it (no tile follows,
+    // the epilogues stage through disjoint halves of the ring): without the pair group A runs its epilogue -- residual loads,
+    // LDS staging, stores -- while group B is still multiplying, and the tile's HBM burst comes in two halves.
+    if (grp == 0 || t + 1 < nt) __builtin_amdgcn_s_barrier();
   }
-  if (grp == 0) __builtin_amdgcn_s_barrier();
   if constexpr (GEMM6_TIMING) tk2 = __builtin_readcyclecounter();
   if (EPI != EPI_F32_SCALE && g.staged_epilogue) {
     gemm_epilogue_staged<EPI>(g, acc, smem + wave * (128 * 128), m0 + 128 * wm, n0 + 64 * wn, lane);
