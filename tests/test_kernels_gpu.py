@@ -275,3 +275,43 @@ def test_attention_split_kv_tail_round(lib, variant):
     ref32 = W.sdpa_fp32(q[rows].reshape(1, -1, H, 128).cpu(), kc.reshape(1, -1, H, 128).cpu(), vc.reshape(1, -1, H, 128).cpu()).reshape(-1, d)
     assert rel_l2(o_ws[rows], ref32) < 1e-2 and rel_l2(o_plain[rows], ref32) < 1e-2
     assert rel_l2(o_ws, o_plain) < 3e-3
+
+
+@pytest.mark.parametrize("variant", [2, 4])
+def test_attention_split_kv_tail_round_spiked(lib, variant):
+    """The tail round with scores no FAST pass can hold: a few keys are large multiples of a few queries, in the rows of the
+    split tail blocks and in rows of the main round, in different KV ranges of the split.  The w64 kernel's blocks that see them
+    redo their KV range in the GENERAL pass and write partials with their own references; the merge must still give the exact
+    softmax (checker: fp32).  Variant 4 = w64 on a q its producer prescaled; 2 = the ping-pong kernel (online max per tile)."""
+    from mmpl_amd import _lib
+    from oracle import wan_dit_ref as W
+    torch.manual_seed(12)
+    dev = "cuda:0"
+    H, S, n_pages, Lq = 8, 640, 3, 256 * 41 - 57
+    d = H * 128
+    q32 = torch.randn(Lq, d, device=dev)
+    kc32 = torch.randn(n_pages * S, d, device=dev)
+    vc = torch.randn(n_pages * S, d, device=dev).to(BF)
+    hot_rows = [5, 300, Lq - 2000, Lq - 700, Lq - 3]                      # main-round rows and tail-block rows
+    hot_keys = [17, 700, 1300, 1900, 650]                                  # spread over the three pages = over the split's KV ranges
+    for r, kk in zip(hot_rows, hot_keys):
+        for h in (0, 3, 7):
+            kc32[kk, h * 128:(h + 1) * 128] = q32[r, h * 128:(h + 1) * 128] * 25.0
+    c = (1.0 / math.sqrt(128)) * 1.4426950408889634
+    q = (q32 * c).to(BF) if variant == 4 else q32.to(BF)
+    q_ref = (q.float() / c) if variant == 4 else q.float()
+    kc = kc32.to(BF)
+    kp = (C.c_void_p * n_pages)(*[kc[i * S:].data_ptr() for i in range(n_pages)])
+    vp = (C.c_void_p * n_pages)(*[vc[i * S:].data_ptr() for i in range(n_pages)])
+    o = torch.full((Lq, d), float("nan"), device=dev, dtype=BF)
+    ws = torch.empty(lib.mmpl_attn_workspace_bytes(), dtype=torch.uint8, device=dev)
+    _lib.check(lib.mmpl_attn_fwd_variant(_lib.ptr(q), d, _lib.ptr(o), d, kp, vp, d, d, n_pages, S, Lq, H, 1.0 / math.sqrt(128),
+                                         _lib.ptr(ws), ws.numel(), variant, 0, _sp()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(o.float()).all()
+    rows = torch.cat([torch.arange(0, 600), torch.arange(Lq - 2400, Lq)])
+    ref32 = W.sdpa_fp32(q_ref[rows].reshape(1, -1, H, 128).cpu(), kc.float().reshape(1, -1, H, 128).cpu(), vc.float().reshape(1, -1, H, 128).cpu()).reshape(-1, d)
+    assert rel_l2(o[rows], ref32) < 1e-2
+    for r in hot_rows:                                                     # the spiked rows themselves: one-hot-like softmax, 2 bf16 ulps
+        i = (rows == r).nonzero()[0, 0]
+        assert max_abs(o[r], ref32[i]) < 2.0 ** -7 * ref32[i].abs().max().item() + 1e-3
