@@ -71,6 +71,20 @@ def test_gemm_w64_opt_in_kernel():
     assert " passed" in r.stdout
 
 
+def test_cross_attention_on_w64_opt_in():
+    """MMPL_CROSS_W64=1 (read once per process) puts the text / image cross-attention on the 64-rows-per-wave kernel too
+    (q prescaled by the cross q-norm): the DiT forward and the i2v model-type goldens in a child process with it set."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MMPL_CROSS_W64="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_dit_forward_gpu.py", "tests/test_i2v_clip_gpu.py",
+                        "-k", "golden or oracle_small"], cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_gemm_heavy_tailed(lib):
     """Wan-like activation statistics: a few channels of A carry values ~100x the rest (massive activations) and a few
     weight rows are large; same tolerance as test_gemm (the fp32 accumulation must not lose the small terms)."""
