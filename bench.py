@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--model", default="14B", choices=["14B", "1.3B", "small", "tiny"])
     ap.add_argument("--res", default="720p", choices=["480p", "720p", "tiny"])
     ap.add_argument("--mode", default="t2v", choices=["t2v", "i2v"], help="stage plan of the rotation (i2v: 1/7/6/6 query frames, BASELINE configs[4])")
+    ap.add_argument("--i2v-model", action="store_true",
+                    help="Wan-I2V MODEL TYPE (in_dim 36 + the CLIP image stream in every block's cross-attention, model.py:563-616) instead of the "
+                         "T2V backbone the reference's I2V scripts run; synthetic CLIP features; not the headline workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="disable the per-kernel hipEvent pairs")
     ap.add_argument("--profile-all", action="store_true",
@@ -159,8 +162,15 @@ def main():
     lib = _lib.load()
     cfg = WAN_CONFIGS[args.model]
     lat_h, lat_w = (16, 24) if args.res == "tiny" else RESOLUTIONS[args.res]
-    eng = DitEngine(cfg, lat_h, lat_w, dev)
-    eng.load_state_dict(dit_state_dict(cfg, seed=1234, device=dev))
+    if args.i2v_model:
+        from mmpl_amd.synthetic import dit_i2v_state_dict
+        cfg = dict(cfg, model_type="i2v")
+        eng = DitEngine(cfg, lat_h, lat_w, dev)
+        eng.load_state_dict(dit_i2v_state_dict(cfg, seed=1234, device=dev))
+        eng.set_image_kv(*eng.precompute_image_context(torch.randn(257, 1280, device=dev).to(torch.bfloat16)))
+    else:
+        eng = DitEngine(cfg, lat_h, lat_w, dev)
+        eng.load_state_dict(dit_state_dict(cfg, seed=1234, device=dev))
     S = eng.S
     plan = StagePlan(args.mode)
     stage_shapes = T2V_STAGE_SHAPES if args.mode == "t2v" else I2V_STAGE_SHAPES
@@ -187,12 +197,22 @@ def main():
         if pair is not None:
             pair.broadcast(lat)
         flow = torch.empty((2,) + tuple(lat.shape), device=dev, dtype=lat.dtype)
-        stage_state.append(dict(frames=frames, lat=lat, sched=sched, vis=vis, ws=plan.write_slots(frames),
+        x36 = None
+        if args.i2v_model:                                  # x = [latents | conditioning video y (mask + image latents, 20 channels)]
+            x36 = torch.randn(len(frames), 36, lat_h, lat_w, device=dev).to(torch.bfloat16)
+        stage_state.append(dict(frames=frames, lat=lat, x36=x36, sched=sched, vis=vis, ws=plan.write_slots(frames),
                                 fc=flow[0], fu=flow[1], flow=flow, mine=torch.empty_like(lat),
                                 t=torch.empty(len(frames), dtype=torch.float32, device=dev)))
     handoff_send = torch.zeros(8, 16, lat_h, lat_w, device=dev, dtype=torch.bfloat16)
     handoff_recv = torch.zeros_like(handoff_send)
     side = torch.cuda.Stream(device=dev)
+
+    def xin(st):
+        """the forward's input: the latents, or (I2V model type) the 36-channel buffer whose first 16 channels are refreshed from them"""
+        if st["x36"] is None:
+            return st["lat"]
+        st["x36"][:, :16].copy_(st["lat"])
+        return st["x36"]
 
     def one_step(i, eager=False):
         st = stage_state[i % 4]
@@ -214,10 +234,10 @@ def main():
         if pair is None:
             for which, out in ((0, st["fc"]), (1, st["fu"])):
                 kc, vc, ck, cv = caches[which]
-                eng.forward(st["lat"], st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out)
+                eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out)
         else:
             kc, vc, ck, cv = caches[0]
-            eng.forward(st["lat"], st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=st["mine"])
+            eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=st["mine"])
             pair.exchange(st["mine"], st["flow"])
         sched.step_cfg(st["fc"], st["fu"], 5.0, st["lat"])
         if i % 4 == 1:
@@ -255,7 +275,7 @@ def main():
             for which, out in ((0, st["fc"]), (1, st["fu"])):
                 kc, vc, ck, cv = caches[which]
                 st["t"].fill_(999.0)
-                eng.forward(st["lat"], st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out)
+                eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out)
             sched = st["sched"]
             sched.build_step_table(5.0, dev)
             sched._ensure_state(st["lat"])
@@ -265,7 +285,7 @@ def main():
             with torch.cuda.graph(g):
                 for which, out in ((0, st["fc"]), (1, st["fu"])):
                     kc, vc, ck, cv = caches[which]
-                    eng.forward(st["lat"], st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out)
+                    eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out)
                 sched.step_cfg_table(st["fc"], st["fu"], st["lat"], st["t"])
             st["graph"], st["replays"] = g, 0
     for i in range(args.warmup):
@@ -364,6 +384,7 @@ def main():
                        "frame_seqlen": S, "latent_hw": [lat_h, lat_w], "sampling_steps": 50, "guidance_scale": 5.0,
                        "timed_path": ("one hipGraph replay per denoise step (2 DiT forwards + fused CFG/UniPC, device-resident step tables)"
                                       if use_graph else "eager launches"),
+                       "model_type": "i2v (in_dim 36 + CLIP image stream)" if args.i2v_model else "t2v",
                        "parallelism": (f"chunk-per-rank x{world}" if pair is None else f"{n_lanes} chunk lanes x 2 (cond|uncond) CFG split, "
                                        "per-step 2-rank all-gather of flow predictions") +
                                       (" + RCCL p2p anchor hand-off lane->lane+1" if world > 1 else "") +
