@@ -302,8 +302,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     head = xcd + 8 * (local / n_qb);
     qb = local % n_qb;
   } else {
-    head = blockIdx.x / n_qb;
-    qb = blockIdx.x % n_qb;
+    // any other head count (Wan 1.3B: 12): the hardware deals blocks round-robin to the 8 XCDs, so XCD x is given the x-th
+    // contiguous chunk of the head-major (head, query block) list -- the blocks sharing one L2 work on at most a few heads;
+    // the grid is padded to 8 chunks (launcher), the padding blocks leave at once
+    const int total = n_qb * a.H, per = (total + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (item >= total) return;
+    head = item / n_qb;
+    qb = item % n_qb;
   }
 
   const int qrow = min(qb * QB + wave * QW + l31, a.Lq - 1);
@@ -666,7 +672,7 @@ hipError_t mmpl_launch_attention(const AttnArgs& a, hipStream_t s) {
     if (tiles / sp < 8 || (size_t)8 * tb * sp * QB * 130 * sizeof(float) > a.split_ws_bytes) sp = 1;
   }
   if (sp == 1) {
-    run(n_qb * a.H, 0, 1, false);
+    run((a.H & 7) == 0 ? n_qb * a.H : 8 * ((n_qb * a.H + 7) / 8), 0, 1, false);        // other head counts: grid padded to 8 XCD chunks
   } else {
     run(8 * (b - tb), 0, 1, false);
     run(8 * tb * sp, b - tb, sp, true);

@@ -381,8 +381,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     head = xcd + 8 * (local / n_qb);
     qb = local % n_qb;
   } else {
-    head = blockIdx.x / n_qb;
-    qb = blockIdx.x % n_qb;
+    // any other head count (Wan 1.3B: 12): the hardware deals blocks round-robin to the 8 XCDs, so XCD x is given the x-th
+    // contiguous chunk of the head-major (head, query block) list -- the blocks sharing one L2 work on at most a few heads;
+    // the grid is padded to 8 chunks (launcher), the padding blocks leave at once
+    const int total = n_qb * a.H, per = (total + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (item >= total) return;
+    head = item / n_qb;
+    qb = item % n_qb;
   }
 
   // the accumulator file is ours: this statement makes the kernel descriptor allocate all 256 entries
