@@ -98,6 +98,13 @@ int mmpl_attn_fwd_variant(const void* q, int ldq, void* o, int ldo, const void* 
 int mmpl_gemm(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N, int K,
               int epi, const void* res, int ldres, const void* gate, int gate_frame_stride, int rows_per_frame,
               mmpl_stream_t stream);
+/* The same GEMM with dynamic tile scheduling for the large-problem kernel: tile_counter = 8 device ints (one per XCD) that are
+ * zero when the launch starts (the launch leaves them zero); the kernel is then launched once per CU and its blocks draw
+ * tiles of their XCD's share until none is left, instead of one block per tile in lock-step rounds.  Launches sharing a
+ * counter must be stream-ordered.  NULL = mmpl_gemm.  (mmpl_dit_forward keeps such a counter in its workspace.) */
+int mmpl_gemm_tickets(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N, int K,
+                      int epi, const void* res, int ldres, const void* gate, int gate_frame_stride, int rows_per_frame,
+                      void* tile_counter, mmpl_stream_t stream);
 
 /* WanLayerNorm (+ per-frame modulation or affine) (wan/modules/model.py:89-99, causal_fps_model.py:343,352,355) */
 int mmpl_layernorm(const void* x, int ldx, void* y, int ldy, int rows, int d, float eps, const void* scale,

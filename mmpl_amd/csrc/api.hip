@@ -206,6 +206,7 @@ struct Carver {
 };
 struct FwdWs {
   bf16_t *x, *xn, *big, *attn, *ksc, *vsc, *patch, *sinu, *t1, *e, *se, *e0, *emod, *emod_head, *yh;
+  int* tile_counter;     // 8 ints: the per-XCD tile tickets of the large GEMMs (GemmArgs.tile_counter), zeroed at the start of a forward
   size_t bytes;
 };
 FwdWs carve_fwd(const MmplDit* h, int nF, void* base) {
@@ -229,13 +230,15 @@ FwdWs carve_fwd(const MmplDit* h, int nF, void* base) {
   w.emod = k.take((size_t)c.num_layers * nF * 6 * d);
   w.emod_head = k.take((size_t)nF * 2 * d);
   w.yh = k.take(Lq * 64);
+  w.tile_counter = (int*)k.take(128);
   w.bytes = k.off;
   return w;
 }
 
 int gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, bf16_t* C, int ldc, int M, int N, int K,
-         int epi, const bf16_t* res, int ldres, const bf16_t* gate, int gfs, int rpf, hipStream_t s) {
+         int epi, const bf16_t* res, int ldres, const bf16_t* gate, int gfs, int rpf, hipStream_t s, int* tile_counter = nullptr) {
   GemmArgs g{A, lda, W, ldw, bias, C, ldc, M, N, K, epi, res, ldres, gate, gfs, rpf > 0 ? rpf : 1, 1.0f, 0, 0, 0, 0, 0};
+  g.tile_counter = tile_counter;
   ProfScope ps(K_GEMM, 2.0 * M * (double)N * K, s);
   hipError_t e = mmpl_launch_gemm(g, s);
   if (e != hipSuccess) return fail("gemm", hipGetErrorString(e));
@@ -307,6 +310,8 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
   hipStream_t s = (hipStream_t)stream;
   const int S = h->S, d = c.dim, f = c.ffn_dim, Lq = nF * S, H = c.num_heads, T = c.text_len;
 
+  HIP_TRY(hipMemsetAsync(w.tile_counter, 0, 8 * sizeof(int), s), "tile counter");      // left zero by every GEMM that uses it
+  int* const tc = w.tile_counter;
   // ---- embeddings (causal_fps_model.py:757-776)
   HIP_TRY(mmpl_launch_patchify((const bf16_t*)x_in, w.patch, h->pe_k, nF, c.in_dim, c.lat_h, c.lat_w, s), "patchify");
   TRY(gemm(w.patch, h->pe_k, h->G(G_PE_W), h->pe_k, h->G(G_PE_B), w.x, d, Lq, d, h->pe_k, EPI_BIAS, nullptr, 0, nullptr, 0, 1, s));
@@ -344,6 +349,7 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
       for (int i = 0; i < nF; ++i) g.v_dst[i] = persist ? vc + (size_t)write_slots[i] * S * d : w.vsc + (size_t)i * S * d;
       g.v_col0 = 2 * d;
       g.v_ld = d;
+      g.tile_counter = tc;
       ProfScope ps(K_GEMM, 2.0 * Lq * 3.0 * d * d, s);
       HIP_TRY(mmpl_launch_gemm(g, s), "qkv gemm");
     }
@@ -382,14 +388,14 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
       ProfScope ps(K_ATTN_SELF, 4.0 * Lq * (double)np * S * d, s);
       HIP_TRY(mmpl_launch_attention(a, s), "self attention");
     }
-    TRY(gemm(w.attn, d, h->Lw(l, L_O_W), d, h->Lw(l, L_O_B), w.x, d, Lq, d, d, EPI_GATE_RES, w.x, d, em + 2 * d, 6 * d, S, s));
+    TRY(gemm(w.attn, d, h->Lw(l, L_O_W), d, h->Lw(l, L_O_B), w.x, d, Lq, d, d, EPI_GATE_RES, w.x, d, em + 2 * d, 6 * d, S, s, tc));
     // -- cross attention (causal_fps_model.py:352-353, model.py:161-194)
     {
       LnArgs a{w.x, d, w.xn, d, Lq, d, c.eps, nullptr, nullptr, 0, S, h->Lw(l, L_N3_W), h->Lw(l, L_N3_B)};
       ProfScope ps(K_LAYERNORM, 0, s);
       HIP_TRY(mmpl_launch_layernorm(a, s), "norm3");
     }
-    TRY(gemm(w.xn, d, h->Lw(l, L_CQ_W), d, h->Lw(l, L_CQ_B), w.big, d, Lq, d, d, EPI_BIAS, nullptr, 0, nullptr, 0, 1, s));
+    TRY(gemm(w.xn, d, h->Lw(l, L_CQ_W), d, h->Lw(l, L_CQ_B), w.big, d, Lq, d, d, EPI_BIAS, nullptr, 0, nullptr, 0, 1, s, tc));
     {
       ProfScope ps(K_QKNORM, 0, s);
       HIP_TRY(mmpl_launch_rmsnorm(w.big, d, h->Lw(l, L_CNQ), Lq, d, c.eps, s, cross_w64 ? scale * 1.4426950408889634f : 0.f), "cross q norm");
@@ -416,15 +422,15 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
         HIP_TRY(mmpl_launch_add(w.attn, w.ksc, (size_t)Lq * d, s), "x + img_x");
       }
     }
-    TRY(gemm(w.attn, d, h->Lw(l, L_CO_W), d, h->Lw(l, L_CO_B), w.x, d, Lq, d, d, EPI_RES, w.x, d, nullptr, 0, 1, s));
+    TRY(gemm(w.attn, d, h->Lw(l, L_CO_W), d, h->Lw(l, L_CO_B), w.x, d, Lq, d, d, EPI_RES, w.x, d, nullptr, 0, 1, s, tc));
     // -- FFN (causal_fps_model.py:354-360)
     {
       LnArgs a{w.x, d, w.xn, d, Lq, d, c.eps, em + 4 * d, em + 3 * d, 6 * d, S, nullptr, nullptr};
       ProfScope ps(K_LAYERNORM, 0, s);
       HIP_TRY(mmpl_launch_layernorm(a, s), "norm2");
     }
-    TRY(gemm(w.xn, d, h->Lw(l, L_F0_W), d, h->Lw(l, L_F0_B), w.big, f, Lq, f, d, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 1, s));
-    TRY(gemm(w.big, f, h->Lw(l, L_F2_W), f, h->Lw(l, L_F2_B), w.x, d, Lq, d, f, EPI_GATE_RES, w.x, d, em + 5 * d, 6 * d, S, s));
+    TRY(gemm(w.xn, d, h->Lw(l, L_F0_W), d, h->Lw(l, L_F0_B), w.big, f, Lq, f, d, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 1, s, tc));
+    TRY(gemm(w.big, f, h->Lw(l, L_F2_W), f, h->Lw(l, L_F2_B), w.x, d, Lq, d, f, EPI_GATE_RES, w.x, d, em + 5 * d, 6 * d, S, s, tc));
   }
   // ---- head + unpatchify (causal_fps_model.py:384-395, 1007-1030)
   {
@@ -477,6 +483,15 @@ int mmpl_gemm(const void* A, int lda, const void* W, int ldw, const void* bias, 
   if ((epi == EPI_GATE_RES && (!res || !gate)) || (epi == EPI_RES && !res)) return fail("mmpl_gemm", "missing epilogue operand");
   return gemm((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (bf16_t*)C, ldc, M, N, K, epi,
               (const bf16_t*)res, ldres, (const bf16_t*)gate, gate_frame_stride, rows_per_frame, (hipStream_t)stream);
+}
+
+int mmpl_gemm_tickets(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N, int K,
+                      int epi, const void* res, int ldres, const void* gate, int gate_frame_stride, int rows_per_frame,
+                      void* tile_counter, mmpl_stream_t stream) {
+  if (epi < EPI_BIAS || epi > EPI_F32_SCALE) return fail("mmpl_gemm", "unknown epilogue");
+  if ((epi == EPI_GATE_RES && (!res || !gate)) || (epi == EPI_RES && !res)) return fail("mmpl_gemm", "missing epilogue operand");
+  return gemm((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (bf16_t*)C, ldc, M, N, K, epi,
+              (const bf16_t*)res, ldres, (const bf16_t*)gate, gate_frame_stride, rows_per_frame, (hipStream_t)stream, (int*)tile_counter);
 }
 
 int mmpl_layernorm(const void* x, int ldx, void* y, int ldy, int rows, int d, float eps, const void* scale,

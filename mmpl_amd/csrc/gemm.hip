@@ -440,7 +440,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if constexpr (GEMM6_TIMING) tk0 = __builtin_readcyclecounter();
   const int tiles_m = (g.M + BM3 - 1) / BM3, tiles_n = (g.N + BN3 - 1) / BN3;
   const int nwg = tiles_m * tiles_n;
+  // Tile order: XCD x owns the x-th contiguous chunk of the grouped-M tile list (q + 1 tiles for x < r, else q), so that the
+  // blocks sharing one L2 work on neighbouring tiles.  Without a tile counter block b IS tile b (the hardware deals blocks
+  // round-robin to the XCDs).  With one (g.tile_counter) the kernel is launched once per CU and a block takes the next tile of
+  // ITS XCD's chunk when it is done with the previous one: equal tiles do not take equal time (blocks that are first to touch an
+  // operand panel wait on HBM, 33-42 cycles per MFMA across blocks), and a lock-step round lasts as long as its slowest block.
+  // Ticket protocol: exactly chunk + (blocks of the XCD) tickets are drawn per launch; whoever draws the last one knows every
+  // other block of the XCD is leaving and zeroes the counter for the next launch.
+  __shared__ int s_ticket;
+  const bool persistent = g.tile_counter != nullptr;
+  const int my_xcd = blockIdx.x & 7;
+  const int chunk = (nwg >> 3) + (my_xcd < (nwg & 7) ? 1 : 0);
+  const int blocks_x = (int)(gridDim.x >> 3) + (my_xcd < (int)(gridDim.x & 7) ? 1 : 0);
+  for (;;) {
   int bid = blockIdx.x;
+  if (persistent) {
+    if (threadIdx.x == 0) s_ticket = atomicAdd(g.tile_counter + my_xcd, 1);
+    __syncthreads();
+    const int ticket = s_ticket;
+    if (ticket >= chunk) {
+      if (ticket == chunk + blocks_x - 1 && threadIdx.x == 0) g.tile_counter[my_xcd] = 0;
+      return;
+    }
+    bid = ticket * 8 + my_xcd;
+  }
   {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -559,6 +582,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       tp[3] = (float)(2 * nt);                                // in 32-wide k stages, like gemm_w64
     }
   }
+  if (!persistent) return;
+  __syncthreads();                 // the ring (and s_ticket) are free again: every wave is done with its epilogue's staging
+  }
 }
 
 template <int EPI>
@@ -573,7 +599,12 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
   g2.staged_epilogue = !env_direct && g.N % 8 == 0 && g.ldc % 8 == 0 && (g.epi != EPI_GATE_RES || g.gate_frame_stride % 8 == 0) &&
                        ((g.epi != EPI_GATE_RES && g.epi != EPI_RES) || g.ldres % 8 == 0) &&
                        (g.epi != EPI_BIAS_VPAGES || (g.v_col0 % 8 == 0 && g.v_ld % 8 == 0));
-  hipLaunchKernelGGL(gemm_bf16_v6_kernel<EPI>, dim3(tiles), dim3(512), smem, s, g2);
+  static const bool env_static = getenv("MMPL_GEMM_STATIC_TILES") != nullptr;
+  if (env_static) g2.tile_counter = nullptr;
+  const int n_cu = 8 * mmpl_cus_per_xcd();
+  const int blocks = g2.tile_counter && tiles > n_cu ? n_cu : tiles;
+  if (blocks == tiles) g2.tile_counter = nullptr;             // one round or less: nothing to balance
+  hipLaunchKernelGGL(gemm_bf16_v6_kernel<EPI>, dim3(blocks), dim3(512), smem, s, g2);
   return hipGetLastError();
 }
 

@@ -29,6 +29,10 @@ struct GemmArgs {
   // EPI_BIAS_VPAGES: row m, column n >= v_col0 is written to v_dst[m / rows_per_frame] + (m % rows_per_frame) * v_ld + n - v_col0
   bf16_t* v_dst[8]; int v_col0, v_ld;
   int staged_epilogue;           // v6: LDS-staged 16-byte epilogue (set by the launcher when every pointer / stride allows it)
+  // v6, optional: 8 device ints (one per XCD), zero when the launch starts and left zero by it.  With it the kernel is launched
+  // once per CU and its blocks take tiles of their XCD's share from these tickets until none is left (gemm.hip); the
+  // launches that share a counter must be ordered (one stream).  Null: one block per tile.
+  int* tile_counter;
 };
 hipError_t mmpl_launch_gemm(const GemmArgs& g, hipStream_t s);
 bool mmpl_gemm_w64_accepts(const GemmArgs& g);                      // gemm_w64.hip: the one-wave-per-SIMD kernel for the large linears

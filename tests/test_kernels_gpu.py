@@ -85,6 +85,31 @@ def test_cross_attention_on_w64_opt_in():
     assert " passed" in r.stdout
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(25200, 5120, 1024, 3), (9000, 2560, 512, 0), (4096, 5120, 5120, 1), (3120, 768, 256, 4)])
+def test_gemm_dynamic_tile_scheduling(lib, M, N, K, epi):
+    """mmpl_gemm_tickets: the large-problem kernel launched once per CU, blocks drawing tiles from per-XCD tickets.  Same tiles,
+    same arithmetic per tile -> bit-identical to mmpl_gemm; the counters are zero again afterwards (two launches in a row).
+    The last shape has fewer tiles than CUs: falls back to one block per tile."""
+    from mmpl_amd import _lib
+    torch.manual_seed(M + N + K)
+    dev = "cuda:0"
+    A = torch.randn(M, K, device=dev).to(BF)
+    W = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(BF)
+    b = (torch.randn(N, device=dev) * 0.1).to(BF)
+    res = torch.randn(M, N, device=dev).to(BF)
+    gate = torch.randn((M + 3599) // 3600, N, device=dev).to(BF)
+    ref = torch.empty(M, N, device=dev, dtype=BF)
+    _lib.check(lib.mmpl_gemm(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(ref), N, M, N, K, epi, _lib.ptr(res), N, _lib.ptr(gate), N, 3600, _sp()))
+    ctr = torch.zeros(8, dtype=torch.int32, device=dev)
+    for _ in range(2):
+        out = torch.full((M, N), float("nan"), device=dev, dtype=BF)
+        _lib.check(lib.mmpl_gemm_tickets(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(out), N, M, N, K, epi, _lib.ptr(res), N,
+                                         _lib.ptr(gate), N, 3600, _lib.ptr(ctr), _sp()))
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+        assert int(ctr.abs().sum()) == 0
+
+
 def test_gemm_heavy_tailed(lib):
     """Wan-like activation statistics: a few channels of A carry values ~100x the rest (massive activations) and a few
     weight rows are large; same tolerance as test_gemm (the fp32 accumulation must not lose the small terms)."""

@@ -61,8 +61,14 @@ def bench_gemm(iters):
         gate = torch.randn(8, N, device=dev).to(BF)
         fn = lambda: _lib.check(lib.mmpl_gemm(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(Cc), N, M, N, K, epi, _lib.ptr(res),
                                               N, _lib.ptr(gate), N, 3600, _lib.stream_ptr()))
-        ms = timeit(fn, iters)
-        print(f"gemm {name}: M={M} N={N} K={K} epi={epi}  {ms:8.3f} ms  {2.0 * M * N * K / ms / 1e9:8.1f} TFLOP/s", flush=True)
+        ctr = torch.zeros(8, dtype=torch.int32, device=dev)
+        fn_t = lambda: _lib.check(lib.mmpl_gemm_tickets(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(Cc), N, M, N, K, epi, _lib.ptr(res),
+                                                        N, _lib.ptr(gate), N, 3600, _lib.ptr(ctr), _lib.stream_ptr()))
+        ms, ms_t = timeit(fn, iters), timeit(fn_t, iters)
+        ms2, ms_t2 = timeit(fn, iters), timeit(fn_t, iters)
+        ms, ms_t = min(ms, ms2), min(ms_t, ms_t2)
+        print(f"gemm {name}: M={M} N={N} K={K} epi={epi}  {ms:8.3f} ms  {2.0 * M * N * K / ms / 1e9:8.1f} TFLOP/s   |  tile tickets {ms_t:8.3f} ms  "
+              f"{2.0 * M * N * K / ms_t / 1e9:8.1f} TFLOP/s", flush=True)
 
 
 def gemm_phases(epi=3):
