@@ -215,6 +215,7 @@ FwdWs carve_fwd(const MmplDit* h, int nF, void* base) {
   const size_t bigw = (size_t)(3 * c.dim > c.ffn_dim ? 3 * c.dim : c.ffn_dim);
   Carver k(base);
   FwdWs w;
+  w.tile_counter = (int*)k.take(128);     // first: the same place for every stage shape, so no other shape's activations ever land on it
   w.x = k.take(Lq * d);
   w.xn = k.take(Lq * d);
   w.big = k.take(Lq * bigw);
@@ -230,7 +231,6 @@ FwdWs carve_fwd(const MmplDit* h, int nF, void* base) {
   w.emod = k.take((size_t)c.num_layers * nF * 6 * d);
   w.emod_head = k.take((size_t)nF * 2 * d);
   w.yh = k.take(Lq * 64);
-  w.tile_counter = (int*)k.take(128);
   w.bytes = k.off;
   return w;
 }
@@ -310,7 +310,7 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
   hipStream_t s = (hipStream_t)stream;
   const int S = h->S, d = c.dim, f = c.ffn_dim, Lq = nF * S, H = c.num_heads, T = c.text_len;
 
-  HIP_TRY(hipMemsetAsync(w.tile_counter, 0, 8 * sizeof(int), s), "tile counter");      // left zero by every GEMM that uses it
+  HIP_TRY(mmpl_launch_zero_ints(w.tile_counter, 8, s), "tile counter");                  // left zero by every GEMM that uses it
   int* const tc = w.tile_counter;
   // ---- embeddings (causal_fps_model.py:757-776)
   HIP_TRY(mmpl_launch_patchify((const bf16_t*)x_in, w.patch, h->pe_k, nF, c.in_dim, c.lat_h, c.lat_w, s), "patchify");

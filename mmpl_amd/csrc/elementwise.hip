@@ -318,6 +318,15 @@ hipError_t mmpl_launch_unpatchify(const bf16_t* y, int ldy, bf16_t* out, int F, 
   hipLaunchKernelGGL(unpatchify_kernel, dim3(grid_for(n)), dim3(256), 0, s, y, ldy, out, F, C, h, w);
   return hipGetLastError();
 }
+__global__ void zero_ints_kernel(int* p, int n) {
+  if ((int)threadIdx.x < n) p[threadIdx.x] = 0;
+}
+// a kernel rather than hipMemsetAsync: inside a captured hipGraph it is an ordinary kernel node, ordered like every other launch
+// (a memset NODE was seen to run unordered under rocprofv3's kernel tracing: garbage tile tickets -> faults / hangs)
+hipError_t mmpl_launch_zero_ints(int* p, int n, hipStream_t s) {
+  hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(64), 0, s, p, n);
+  return hipGetLastError();
+}
 hipError_t mmpl_launch_sinusoid(const float* t, bf16_t* out, int F, int freq_dim, hipStream_t s) {
   const int n = F * (freq_dim / 2);
   hipLaunchKernelGGL(sinusoid_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t, out, F, freq_dim);

@@ -111,6 +111,7 @@ hipError_t mmpl_launch_patchify(const bf16_t* x, bf16_t* a, int lda, int F, int 
 hipError_t mmpl_launch_add(bf16_t* a, const bf16_t* b, size_t n, hipStream_t s);
 hipError_t mmpl_launch_unpatchify(const bf16_t* y, int ldy, bf16_t* out, int F, int C, int h, int w, hipStream_t s);
 // sinusoidal timestep embedding (fp64 math): t[F] fp32 -> out[F, freq_dim] bf16 ([cos | sin])
+hipError_t mmpl_launch_zero_ints(int* p, int n, hipStream_t s);      // n <= 64
 hipError_t mmpl_launch_sinusoid(const float* t, bf16_t* out, int F, int freq_dim, hipStream_t s);
 hipError_t mmpl_launch_silu(const bf16_t* x, bf16_t* y, size_t n, hipStream_t s);
 

@@ -8,17 +8,17 @@ out=gpurun_out/prof_$tag; mkdir -p $out
 for w in $what; do
   case $w in
   stats)
-    timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o b -- python3 bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae > $out/bench_under_rocprof.json 2> $out/stats.err
+    timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o b -- python3 bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae > $out/bench_under_rocprof.json 2> $out/stats.err
     ;;
   hbm)
     for st in s0 s1 s2 s3; do
       for ctr in FETCH_SIZE WRITE_SIZE; do
-        timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc $ctr -d $out/hbm_${st}_$ctr -o p -- python3 tools/attn_one.py $st 2 > $out/hbm_${st}_$ctr.log 2>&1
+        timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc $ctr -d $out/hbm_${st}_$ctr -o p -- python3 tools/attn_one.py $st 2 > $out/hbm_${st}_$ctr.log 2>&1
       done
     done
     ;;
   busy)
-    timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $out/busy -o p -- python3 bench.py --steps 4 --warmup 0 --no-cpu-baseline --no-vae --no-profile > $out/busy_bench.json 2> $out/busy.err
+    timeout -k 10 900 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $out/busy -o p -- python3 bench.py --steps 4 --warmup 0 --no-cpu-baseline --no-vae --no-profile > $out/busy_bench.json 2> $out/busy.err
     ;;
   esac
 done
