@@ -2,10 +2,15 @@
 //
 // Replaces the reference's "fancy-index gather of K and V + flash_attn_varlen" (causal_fps_model.py:219-227,
 // attention.py:139-185): K/V are read IN PLACE from the per-layer KV cache through a table of page (frame
-// slot) base pointers, so no gather copy exists.  The same kernel serves text cross-attention (one page of
-// 512 rows) and the generic attention() seam.
+// slot) base pointers, so no gather copy exists.
 //
-// Structure (CDNA4): 512 threads = 8 waves, each wave owns 32 query rows (Q fragments live in registers);
+// Three kernels share the math, the page table and the fragment layouts; mmpl_launch_attention (end of this file) picks:
+//   attn_w64_kernel (attn_w64.hip)  the DiT forward's self-attention: one wave per SIMD, 64 query rows per wave (default)
+//   attn_pp_kernel  (below)         round 1's default; today a raw-q caller of the attention() seam, and MMPL_ATTN_PP=1
+//   attn_fwd_kernel (below)         the lock-step original: text / image cross-attention, the CLIP tower, MMPL_ATTN_V1=1
+//
+// attn_fwd_kernel:
+// 512 threads = 8 waves, each wave owns 32 query rows (Q fragments live in registers);
 // KV tiles of 64 rows, page-aligned (a frame's ragged tail tile is masked).  K/V tiles are staged
 // global -> registers -> LDS (row-padded: conflict-free ds_read_b128 for K, ds_read_b64_tr_b16 for V), the
 // next tile's global loads are in flight under the current tile's MFMAs, one barrier per tile.
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// v2 "ping-pong" (default for self-attention): same math and fragment layouts as attn_fwd_kernel, but the 8 waves of
+// v2 "ping-pong" (round 1's default for self-attention): same math and fragment layouts as attn_fwd_kernel, but the 8 waves of
 // the (single) resident block are split into two groups that run half an iteration apart.  Per KV tile j a wave runs
 //   M_j = { O += V(j-1).P(j-1) ; S(j) = K(j).Q }   32 MFMAs, LDS fragments requested 6 ahead, 4 LDS-DMA ops
 //   V_j = { online softmax of S(j) -> P(j) }        ~200 VALU (32 exp2)
