@@ -354,3 +354,37 @@ def test_attention_split_kv_tail_round_spiked(lib, variant):
     for r in hot_rows:                                                     # the spiked rows themselves: one-hot-like softmax, 2 bf16 ulps
         i = (rows == r).nonzero()[0, 0]
         assert max_abs(o[r], ref32[i]) < 2.0 ** -7 * ref32[i].abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("variant", [1, 2, 4])
+def test_attention_all_scores_very_negative(lib, variant):
+    """Rows whose every score is far below zero (here ~ -90 in the exponent's log2 units): exp2 of them underflows a pass that
+    takes 0 as the reference, so the w64 kernel's end-of-pass check (row sum < 2^-40) must send the block through the GENERAL
+    pass; the answer is an ordinary softmax over the differences.  Checker: fp32."""
+    from mmpl_amd import _lib
+    from oracle import wan_dit_ref as W
+    torch.manual_seed(21)
+    dev = "cuda:0"
+    Lq, S, H = 300, 200, 1
+    u = torch.randn(128, device=dev)
+    u = u / u.norm()
+    q32 = torch.randn(Lq, 128, device=dev) * 0.3
+    k32 = torch.randn(S, 128, device=dev) * 0.3
+    q32[:40] += 26.0 * u                      # these rows: q.k / sqrt(128) ~ -26*26/11.3 ~ -60 (natural units) for every key
+    k32 -= 26.0 * u
+    q32[40:80] -= 26.0 * u                    # and these the opposite: every score ~ +60 -> overflow side of the same check
+    v = torch.randn(S, 128, device=dev).to(BF)
+    c = (1.0 / math.sqrt(128)) * 1.4426950408889634
+    q = (q32 * c).to(BF) if variant == 4 else q32.to(BF)
+    q_ref = (q.float() / c) if variant == 4 else q.float()
+    k = k32.to(BF)
+    kp = (C.c_void_p * 1)(k.data_ptr())
+    vp = (C.c_void_p * 1)(v.data_ptr())
+    o = torch.full((Lq, 128), float("nan"), device=dev, dtype=BF)
+    _lib.check(lib.mmpl_attn_fwd_variant(_lib.ptr(q), 128, _lib.ptr(o), 128, kp, vp, 128, 128, 1, S, Lq, H, 1.0 / math.sqrt(128), None, 0,
+                                         variant, 0, _sp()))
+    torch.cuda.synchronize()
+    ref = W.sdpa_fp32(q_ref.reshape(1, Lq, 1, 128).cpu(), k.float().reshape(1, S, 1, 128).cpu(), v.float().reshape(1, S, 1, 128).cpu()).reshape(Lq, 128)
+    assert torch.isfinite(o.float()).all()
+    for rows in (slice(0, 40), slice(40, 80), slice(80, Lq)):
+        assert rel_l2(o[rows], ref[rows]) < 1e-2, (rows, rel_l2(o[rows], ref[rows]))
