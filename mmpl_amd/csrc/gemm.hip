@@ -593,7 +593,11 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
   if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v6_kernel<EPI>), smem); e != hipSuccess) return e;
   const int tiles = ((g.M + BM3 - 1) / BM3) * ((g.N + BN3 - 1) / BN3);
   GemmArgs g2 = g;
-  g2.group = 4;
+  static const int env_group = getenv("MMPL_GEMM_GROUP") ? atoi(getenv("MMPL_GEMM_GROUP")) : 0;
+  // M-tile group of the block order (how many row panels the tiles in flight on an XCD span).  Sweep with the staged epilogue
+  // and tile tickets on the 14B / 720p block shapes (TFLOP/s at group 2 / 3 / 4): qkv N=15360 1348 / 1323 / 1315, o N=5120
+  // 1256 / 1301 / 1261, ffn0 N=13824 1305 / 1300 / 1279, ffn2 K=13824 1267 / 1277 / 1278; M=7200 and 8192^3 prefer 4.
+  g2.group = env_group > 0 ? env_group : (g.M >= 16384 ? (g.N >= 8192 ? 2 : 3) : 4);
   // the 16-byte epilogue needs 8-element alignment of everything it touches; otherwise the direct 8-byte one
   static const bool env_direct = getenv("MMPL_GEMM_DIRECT_EPILOGUE") != nullptr;
   g2.staged_epilogue = !env_direct && g.N % 8 == 0 && g.ldc % 8 == 0 && (g.epi != EPI_GATE_RES || g.gate_frame_stride % 8 == 0) &&
