@@ -44,6 +44,16 @@ def test_compiler_never_touches_m0(tmp_path, src):
     assert not problems, problems
 
 
+@hipcc
+def test_gemm_register_budget(tmp_path):
+    """gemm_bf16_v6_kernel sits at 253 of 256 VGPRs; the persistent tile loop costs it 7-8 spilled registers outside the MFMA loop
+    (tile bookkeeping).  A change that pushes real state out (an attempt at overlapping the next tile's first fetch with the
+    epilogue spilled 19-153 and ran at 780 TFLOP/s) must not go unnoticed."""
+    import audit_w64
+    _, info = audit_w64.audit(str(tmp_path), os.path.join(CSRC, "gemm.hip"), own_agprs=False)
+    assert max(info["vgpr_spill_count"]) <= 12, info["vgpr_spill_count"]
+
+
 def test_schedule_include_is_current(tmp_path):
     import gen_attn_w64
     committed = open(gen_attn_w64.OUT).read()
