@@ -52,7 +52,11 @@ KIND_NAMES = ["gemm", "attn_self", "attn_cross", "layernorm", "qknorm_rope", "el
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks (one process per GPU).  Inside a torch.distributed.run launch it must equal WORLD_SIZE; outside one, "
+                         "N > 1 makes this process start that launch itself (before it touches the GPU) and relay rank 0's JSON line")
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="launcher self-test without GPUs: every rank joins a gloo group, rank 0 prints how many ranks it saw")
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--model", default="14B", choices=["14B", "1.3B", "small", "tiny"])
@@ -128,11 +132,52 @@ def cpu_baseline(cfg, lat_h, lat_w, stage_shapes, budget_s):
                        f"; {rate / 1e12:.2f} TFLOP/s") + "; a chunk = 102 forwards per stage x all blocks"}
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` outside a torch.distributed.run launch: become that launch.  This process has not touched
+    the GPU (import torch does not), and it never execs: the ranks are CHILD processes (one per GPU, RCCL between them),
+    their stdout is ours (rank 0 prints the one JSON line), and a failing rank makes the whole command fail."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
+def dry_run_launch(world: int, rank: int):
+    """Every rank joins a gloo group and contributes 1; rank 0 reports the sum (what `n_gpus` would be)."""
+    import datetime
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if os.environ.get("MMPL_DRY_RUN_FAIL_RANK") == str(rank):       # launcher test: a rank that dies must fail the command
+        sys.exit(7)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    t = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": dist.get_world_size(), "ranks_seen": int(t.item())}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    in_launch = "RANK" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus is None:
+        args.gpus = world
+    if not in_launch and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but this launch has WORLD_SIZE={world} ranks; n_gpus must be the ranks that run")
+    if args.dry_run_launch:
+        return dry_run_launch(world, rank)
     dist = None
     if world > 1 or "RANK" in os.environ:      # (a 1-rank torchrun launch exercises the RCCL init / barrier / all-reduce path too)
         import torch.distributed as dist
@@ -375,7 +420,8 @@ def main():
         chunk_flops = 102.0 * sum(stage_flops)
         achieved_pf = (2.0 if pair is None else 1.0) * 51.0 * sum(stage_flops) / chunk_s / 1e15    # forwards per rank-step
         res = {
-            "metric": "video_latent_frames_per_sec", "value": value, "unit": "latent-frames/s", "n_gpus": world,
+            "metric": "video_latent_frames_per_sec", "value": value, "unit": "latent-frames/s",
+            "n_gpus": dist.get_world_size() if dist is not None else 1,        # the ranks RCCL actually connected
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"Wan2.1-{args.mode.upper()}-{args.model} {args.res} chunk-AR denoise step (cond+uncond DiT forward, CFG, UniPC), "

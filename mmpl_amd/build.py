@@ -40,6 +40,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "mmpl_hip.h"))
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    # the compile flags are part of the staleness key: a library built with timing / ablation defines
+    # (MMPL_EXTRA_HIPCC_FLAGS, tools/*_sweep.sh) must never survive into a later plain build, whatever the mtimes say
+    stamp = os.path.join(objdir, "flags.stamp")
+    flags_key = " ".join(FLAGS)
+    if not os.path.exists(stamp) or open(stamp).read() != flags_key:
+        force = True
     jobs = []
     for s in srcs:
         src, obj = os.path.join(CSRC, s), os.path.join(objdir, s.replace(".hip", ".o"))
@@ -56,6 +62,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
         return obj
 
+    if jobs and os.path.exists(stamp):
+        os.remove(stamp)                   # an interrupted rebuild leaves no stamp -> the next build starts over
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(cc, jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in srcs]
@@ -66,6 +74,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    with open(stamp, "w") as f:
+        f.write(flags_key)
     return LIB
 
 

@@ -19,6 +19,9 @@ from typing import Dict, Optional, Tuple
 import torch
 
 _DIT_CFG_KEYS = ("dim", "ffn_dim", "num_heads", "num_layers", "text_dim", "freq_dim")
+# optional keys of WanModel's config (wan/modules/model.py:528-545): carried when present so that a Wan-I2V directory
+# (model_type 'i2v', in_dim 36) builds an i2v engine -- dropping them used to make load_state_dict die on patch_embedding
+_DIT_OPT_KEYS = ("model_type", "in_dim", "out_dim", "eps", "text_len")
 
 
 def read_diffusers_dir(wdir: str) -> Tuple[Optional[dict], Optional[Dict[str, torch.Tensor]]]:
@@ -33,6 +36,11 @@ def read_diffusers_dir(wdir: str) -> Tuple[Optional[dict], Optional[Dict[str, to
         missing = [k for k, v in cfg.items() if v is None]
         if missing:
             raise ValueError(f"{cpath}: missing model dimensions {missing}")
+        cfg.update({k: j[k] for k in _DIT_OPT_KEYS if j.get(k) is not None})
+        if cfg.get("model_type", "t2v") not in ("t2v", "i2v"):
+            raise ValueError(f"{cpath}: unsupported model_type {cfg['model_type']!r}")
+        if cfg.get("out_dim", 16) != 16:
+            raise ValueError(f"{cpath}: out_dim {cfg['out_dim']} (the Wan2.1 latent has 16 channels)")
     if os.path.isdir(wdir):
         names = sorted(n for n in os.listdir(wdir) if re.fullmatch(r"diffusion_pytorch_model(-\d+-of-\d+)?\.safetensors", n))
         shards = [n for n in names if "-of-" in n]
@@ -51,6 +59,17 @@ def read_diffusers_dir(wdir: str) -> Tuple[Optional[dict], Optional[Dict[str, to
                     raise ValueError(f"{wdir}/{n}: keys repeated across shards: {sorted(dup)[:3]}")
                 sd.update(part)
     return cfg, sd
+
+
+def read_clip_visual(path: str) -> Dict[str, torch.Tensor]:
+    """The vision tower of ``models_clip_open-clip-xlm-roberta-large-vit-huge-14.pth`` (wan/modules/clip.py:514-516 loads
+    the whole XLMRobertaCLIP state dict; Wan-I2V only ever calls ``model.visual``): the ``visual.*`` tensors with the
+    prefix removed, i.e. the keys ``CLIPVisionTower.load_state_dict`` takes."""
+    sd = read_state_dict(path)
+    out = {k[len("visual."):]: v for k, v in sd.items() if k.startswith("visual.")}
+    if not out:
+        raise ValueError(f"{path}: no 'visual.*' tensors")
+    return out
 
 
 def read_mmpl_checkpoint(path: str, use_ema: bool = False) -> Dict[str, torch.Tensor]:

@@ -46,6 +46,10 @@ def main(argv=None):
     ap.add_argument("--use_ema", action="store_true")
     ap.add_argument("--i2v", action="store_true", help="image-to-video: the VAE-encoded image is latent frame 0 (MMPL_i2v)")
     ap.add_argument("--image", type=str, help="input image for --i2v (any PIL-readable file)")
+    ap.add_argument("--i2v_model", action="store_true",
+                    help="with --i2v: the Wan-I2V MODEL TYPE (in_dim 36, CLIP ViT-H image cross-attention in every block; Wan2.1-I2V-14B, "
+                         "BASELINE configs[4]) instead of the T2V backbone MMPL's own I2V scripts run; the conditioning video y and the CLIP "
+                         "features are rebuilt per chunk from the chunk's first pixel frame (wan/image2video.py:207-246)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--duration", type=int, default=3, help="number of 21-latent-frame chunks")
     ap.add_argument("--resolution", default="480p", choices=["480p", "720p"])
@@ -56,17 +60,22 @@ def main(argv=None):
     ap.add_argument("--cfg_split", action="store_true",
                     help="multi-GPU: WORLD/2 chunk lanes x (cond, uncond) rank pairs -- the reference's device_cond/device_uncond "
                          "seam -- instead of WORLD chunk lanes")
+    ap.add_argument("--dist_backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (one rank per GPU); gloo stages the hand-off through the host and lets several ranks "
+                         "share one GPU (tests on 1-GPU boxes)")
     args = ap.parse_args(argv)
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dist_backend == "gloo":
+        local_rank %= max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
         # ChunkHandoff.recv / CfgPair.broadcast park a rank until the previous lane has finished its anchor stage: minutes per
         # lane at 14B/720p, far beyond the 10-minute default watchdog once there are more than a few lanes
-        dist.init_process_group("nccl", timeout=datetime.timedelta(hours=12))
+        dist.init_process_group(args.dist_backend, timeout=datetime.timedelta(hours=12))
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     torch.set_grad_enabled(False)
@@ -77,17 +86,37 @@ def main(argv=None):
     config.sampling_steps = args.sampling_steps
     geo = Geometry(*args.latent_hw) if args.latent_hw else Geometry.named(args.resolution)
     mcfg = WAN_CONFIGS[args.model]
-    gen = WanFPSWrapper(**config.model_kwargs, is_causal=True, model_config=mcfg if args.synthetic else None, geometry=geo, device=dev)
+    clip = None
+    if args.i2v_model:
+        if not (args.i2v and args.image):
+            ap.error("--i2v_model needs --i2v --image")
+        from .i2v_clip import CLIPVisionTower
+        mcfg = dict(mcfg, model_type="i2v")
+        tiny_clip = args.synthetic and args.model in ("tiny", "small")      # tests: 2 blocks instead of ViT-H's 32
+        clip = CLIPVisionTower(num_layers=3 if tiny_clip else 32, device=dev)
+    gen = WanFPSWrapper("Wan2.1-I2V-14B-720P" if args.i2v_model else "Wan2.1-T2V-14B", **config.model_kwargs, is_causal=True,
+                        model_config=mcfg if args.synthetic else None, geometry=geo, device=dev)
+    if args.i2v_model and gen.model_type != "i2v":
+        raise SystemExit("--i2v_model: the checkpoint directory does not hold a model_type 'i2v' config")
     if args.synthetic:
-        gen.load_state_dict(dit_state_dict(mcfg, seed=1, device=dev))
+        if args.i2v_model:
+            from .synthetic import clip_visual_state_dict, dit_i2v_state_dict
+            gen.load_state_dict(dit_i2v_state_dict(mcfg, seed=1, device=dev))
+            clip.load_state_dict(clip_visual_state_dict(1280, 16, clip.num_layers, seed=3, device=dev))
+        else:
+            gen.load_state_dict(dit_state_dict(mcfg, seed=1, device=dev))
         enc = SyntheticTextEncoder(mcfg.get("text_dim", 4096), dev)
         vae = WanVAEWrapper(geometry=geo, device=dev, state_dict=vae_state_dict(seed=2))
     else:
         enc, vae = None, None       # reference checkpoints under ../wan_models (wan_wrapper.local_wan_path)
+        if args.i2v_model:
+            from .checkpoints import read_clip_visual
+            from .wan_wrapper import local_wan_path
+            clip.load_state_dict(read_clip_visual(f"{local_wan_path}/Wan2.1-I2V-14B-720P/models_clip_open-clip-xlm-roberta-large-vit-huge-14.pth"))
     mode = "i2v" if args.i2v else "t2v"
     pipe = CausalFPSInferencePipeline(config, dev, generator=gen, text_encoder=enc, vae=vae, device_cond=dev, device_uncond=dev, save=None,
                                       mode=mode, geometry=geo)
-    image_latent = None
+    image_latent, first_px = None, None
     if args.i2v:
         # I2V/Wan_fps_inference_1gpu.py:74-79,100-104: Resize -> ToTensor -> Normalize(0.5, 0.5) -> vae.encode_to_latent
         import numpy as np
@@ -97,6 +126,16 @@ def main(argv=None):
         px = torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1).float() / 255.0
         px = ((px - 0.5) / 0.5).unsqueeze(0).unsqueeze(2).to(device=dev, dtype=torch.bfloat16)      # [1, 3, 1, H, W]
         image_latent = pipe.vae.encode_to_latent(px).to(torch.bfloat16)                                # [1, 1, 16, h, w]
+        first_px = px[0, :, 0]
+
+    def image_cond(frame):
+        """the Wan-I2V model type's conditioning for a chunk whose first pixel frame is `frame` ([3, H, W] in [-1, 1])"""
+        if clip is None:
+            return None
+        if frame is None:                    # the uncond rank of a CFG pair: the pipeline overwrites it with the cond rank's broadcast
+            frame = torch.zeros(3, *geo.pixel_hw, device=dev, dtype=torch.bfloat16)
+        from .i2v_condition import build_image_condition
+        return build_image_condition(pipe.vae, clip, frame, args.num_output_frames)
     if args.checkpoint_path:
         from .checkpoints import read_mmpl_checkpoint
         pipe.generator_cond.load_state_dict(read_mmpl_checkpoint(args.checkpoint_path, use_ema=args.use_ema))
@@ -108,6 +147,11 @@ def main(argv=None):
     else:
         prompts = ["a cat running on the grass"]
     os.makedirs(args.output_folder, exist_ok=True)
+
+    def to_u8(video):
+        """[1, T, 3, H, W] in [0, 1] -> uint8 frames (Wan_fps_inference_1gpu.py:209-225 scales by 255 before write_video)"""
+        return (video * 255.0).clamp(0, 255).to(torch.uint8)
+
     shape = [1, args.num_output_frames, 16, geo.lat_h, geo.lat_w]
     for idx, prompt in enumerate(prompts):
         # noise for every chunk is drawn in order from one seeded generator on every rank (the reference draws it on the
@@ -115,11 +159,13 @@ def main(argv=None):
         g = torch.Generator(device="cpu").manual_seed(args.seed)
         noises = [torch.randn(shape, generator=g).to(torch.bfloat16) for _ in range(args.duration)]
         if world == 1:
-            videos, initial = [], image_latent
+            videos, initial, frame0 = [], image_latent, first_px
             for c in range(args.duration):
-                video, _ = pipe.inference(noises[c].to(dev), [prompt], initial_latent=initial, return_latents=True)
+                video, _ = pipe.inference(noises[c].to(dev), [prompt], initial_latent=initial, return_latents=True,
+                                          image_condition=image_cond(frame0))
                 initial = rolling_initial_latent(pipe.vae, video)
-                videos.append(video.cpu())
+                frame0 = video[0, -5].to(torch.bfloat16) * 2.0 - 1.0       # the next chunk starts at this chunk's 5th-last frame
+                videos.append(to_u8(video))
         else:
             pair, heads, lay = (CfgPair.build(world, dev, True) if args.cfg_split else (None, None, None))
             pipe.cfg_pair = pair
@@ -127,19 +173,27 @@ def main(argv=None):
             ho = (ChunkHandoff((1, 3 if args.i2v else 8, 16, geo.lat_h, geo.lat_w), dev, group=heads)
                   if pair is None or pair.role == 0 else None)
 
+            frame_of = {0: first_px}
+
+            def to_initial(c_recv):
+                init, frame = handoff_to_initial_latent(pipe.vae, c_recv.to(dev), return_first_frame=True)
+                frame_of["next"] = frame
+                return init
+
             def make_chunk(c, initial, sink):
                 pipe.handoff_sink = sink
                 if c == 0:
                     initial = image_latent
-                video, _ = pipe.inference(noises[c].to(dev), [prompt], initial_latent=initial, return_latents=True)
-                return video
+                video, _ = pipe.inference(noises[c].to(dev), [prompt], initial_latent=initial, return_latents=True,
+                                          image_condition=image_cond(frame_of[0] if c == 0 else frame_of.get("next")))
+                return to_u8(video)         # quantised on the owner: the device all-gather moves 224 MB per 720p chunk, not 896
 
-            videos = run_chunk_wavefront(make_chunk, args.duration, ho, lambda t: handoff_to_initial_latent(pipe.vae, t.to(dev)),
+            videos = run_chunk_wavefront(make_chunk, args.duration, ho, to_initial,
                                          pair=pair, lane=lay["lane_of"][rank] if lay else rank, n_lanes=world // 2 if lay else world,
                                          initial_like=torch.empty([1, 2, 16, geo.lat_h, geo.lat_w], device=dev, dtype=torch.bfloat16))
         if videos is not None:
-            full = stitch_chunks(videos)                                     # [1, T, 3, H, W] in [0, 1]
-            out = (full[0].permute(0, 2, 3, 1) * 255.0).clamp(0, 255).to(torch.uint8)
+            full = stitch_chunks(videos)                                     # [1, T, 3, H, W] uint8
+            out = full[0].permute(0, 2, 3, 1).contiguous().cpu()
             path = os.path.join(args.output_folder, f"{idx}-0.pt")
             torch.save(out, path)
             from .utils.video_io import write_video

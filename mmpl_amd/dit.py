@@ -120,8 +120,9 @@ class DitEngine:
         cv = torch.empty_like(ck)
         if self._ctx_ws is None:
             self._ctx_ws = torch.empty(self._lib.mmpl_dit_context_workspace_bytes(self._h), dtype=torch.uint8, device=self.device)
-        _lib.check(self._lib.mmpl_dit_precompute_context(self._h, _lib.ptr(ctx), _lib.ptr(ck), _lib.ptr(cv), _lib.ptr(self._ctx_ws),
-                                                         self._ctx_ws.numel(), _lib.stream_ptr()), "precompute_context")
+        with torch.cuda.device(self.device):          # the stream handed to the library is this device's current stream
+            _lib.check(self._lib.mmpl_dit_precompute_context(self._h, _lib.ptr(ctx), _lib.ptr(ck), _lib.ptr(cv), _lib.ptr(self._ctx_ws),
+                                                             self._ctx_ws.numel(), _lib.stream_ptr()), "precompute_context")
         return ck, cv
 
     def precompute_image_context(self, clip_fea: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -196,18 +197,24 @@ class DitEngine:
 
     # ------------------------------------------------------------------ hipGraph
     def capture(self, x: torch.Tensor, t: torch.Tensor, frame_ids, write_slots, visible_slots, k_cache, v_cache, cross_k, cross_v,
-                out: torch.Tensor) -> "torch.cuda.CUDAGraph":
+                out: torch.Tensor, pre=None) -> "torch.cuda.CUDAGraph":
         """Capture one forward (fixed stage shape, slot table and buffers) into a hipGraph.  The forward is a pure launch
         sequence -- no host sync, no allocation -- so replaying it costs one graph launch instead of ~13 launches per
         layer.  `x`, `t`, `out` and the caches are captured BY ADDRESS: update their contents in place between replays
-        (that is what the denoise loop does: latents and the timestep change, the shapes never do)."""
+        (that is what the denoise loop does: latents and the timestep change, the shapes never do).
+        `pre`: launches recorded in front of the forward (the i2v model type refreshes the latent channels of its 36-channel
+        input buffer there)."""
         self.workspace(x.shape[0])                      # allocate outside the capture
         if not getattr(self, "_warm", False):           # one eager call per engine: lazy kernel attributes are set outside
+            if pre is not None:
+                pre()
             self.forward(x, t, frame_ids, write_slots, visible_slots, k_cache, v_cache, cross_k, cross_v, out=out)
             self._warm = True
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
+            if pre is not None:
+                pre()
             self.forward(x, t, frame_ids, write_slots, visible_slots, k_cache, v_cache, cross_k, cross_v, out=out)
         return g
 

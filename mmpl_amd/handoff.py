@@ -20,9 +20,10 @@ import torch
 OK, FAILED = 1, -1
 
 
-def handoff_to_initial_latent(vae, recv: torch.Tensor) -> torch.Tensor:
+def handoff_to_initial_latent(vae, recv: torch.Tensor, return_first_frame: bool = False):
     """recv: [1, n, 16, h, w] = cat([frame0, anchors...]) (T2V n=8) or cat([frame0, f19, f20]) (I2V n=3).
-    -> initial_latent [1, 2, 16, h, w] bf16 for the next chunk."""
+    -> initial_latent [1, 2, 16, h, w] bf16 for the next chunk (with return_first_frame also the next chunk's first pixel
+    frame [3, H, W] in [-1, 1]: the image the Wan-I2V model type is conditioned on from chunk 2 on)."""
     r = recv.to(torch.bfloat16)
     # mask latents [f0, f19, f19, f20, 0 ...]: only the first 4 matter for pixel frames 8..12 (causal decoder)
     lat = torch.stack([r[0, 0], r[0, -2], r[0, -2], r[0, -1]], dim=0).unsqueeze(0)
@@ -30,6 +31,8 @@ def handoff_to_initial_latent(vae, recv: torch.Tensor) -> torch.Tensor:
     px = (px * 0.5 + 0.5).clamp(0, 1).to(torch.bfloat16)
     clip = px[:, 8:13] * 2.0 - 1.0                                            # 5 frames -> first 2 latents (causal encoder)
     z = vae.encode_to_latent(clip.permute(0, 2, 1, 3, 4))
+    if return_first_frame:
+        return z[:, :2].to(torch.bfloat16), clip[0, 0]
     return z[:, :2].to(torch.bfloat16)
 
 
@@ -160,8 +163,9 @@ class ChunkHandoff:
                               self.dist.isend(payload, dst, group=self.group, tag=2 * chunk + 1)]
 
     def recv(self, chunk: int) -> torch.Tensor:
-        """Receive the hand-off produced by chunk-1.  Bounded by the process group's timeout; raises if the producer
-        reported failure."""
+        """Receive the hand-off produced by chunk-1.  Blocks until the producer's anchor stage is done (minutes per lane at
+        14B/720p), bounded only by the process group's timeout -- the entry points raise it from torch's 10-minute default
+        to 12 h (mmpl_amd/cli.py) / 4 h (bench.py); raises if the producer reported failure."""
         src_local = self.owner(chunk - 1)
         src = self._g(src_local)
         if src_local == self.rank:
@@ -224,11 +228,50 @@ def run_chunk_wavefront(make_chunk: Callable[[int, Optional[torch.Tensor], Calla
     handoff.flush()
     if not gather:
         return None
-    objs = [None] * handoff.world if handoff.rank == 0 else None
-    dist.gather_object({c: v.cpu() for c, v in mine.items()}, objs, dst=0, group=handoff.group)
-    if handoff.rank != 0:
-        return None
-    merged = {}
-    for o in objs:
-        merged.update(o)
-    return [merged[c] for c in range(n_chunks)]
+    return gather_chunks(mine, n_chunks, handoff)
+
+
+def gather_chunks(mine: dict, n_chunks: int, handoff: "ChunkHandoff") -> Optional[List[torch.Tensor]]:
+    """All-gather of the chunk results over the hand-off group, on the device (RCCL ``all_gather_into_tensor`` over xGMI; the
+    in-process list + ``torch.cat(video_chunks)`` of fastapi_parallel_i2v_server.py:851-856): round r collects chunks
+    r*W .. r*W + W - 1, one per rank, into ONE [W, ...] device buffer -- nothing is pickled and nothing passes through the
+    host (a decoded 720p chunk is 224 MB as uint8 frames, 896 MB as fp32).  Every chunk result must have the same shape and
+    dtype (ranks without a chunk in the last round contribute a dummy).  Rank 0 of the group gets the list ordered by chunk
+    index (tensors on the hand-off's device: the GPU for RCCL, the host for gloo), the other ranks None."""
+    dist, W, me = handoff.dist, handoff.world, handoff.rank
+    meta = torch.zeros(10, dtype=torch.int64, device=handoff.device)        # [has, dtype code, ndim, shape...] from a rank that owns a chunk
+    if mine:
+        t0 = next(iter(mine.values()))
+        assert t0.dim() <= 7
+        meta[:3 + t0.dim()] = torch.tensor([1, _DTYPES.index(t0.dtype), t0.dim(), *t0.shape], dtype=torch.int64)
+    metas = [torch.zeros_like(meta) for _ in range(W)]
+    dist.all_gather(metas, meta, group=handoff.group)
+    ref = next((m for m in metas if int(m[0])), None)
+    if ref is None:
+        return [] if me == 0 else None
+    ref = [int(v) for v in ref.tolist()]
+    dtype, shape = _DTYPES[ref[1]], tuple(ref[3:3 + ref[2]])
+    out: List[Optional[torch.Tensor]] = [None] * n_chunks
+    for r in range((n_chunks + W - 1) // W):
+        c = r * W + me
+        part = mine.get(c) if c < n_chunks else None
+        if part is None:
+            part = torch.zeros(shape, dtype=dtype, device=handoff.device)
+        else:
+            assert tuple(part.shape) == shape and part.dtype == dtype, "every chunk result must have the same shape and dtype"
+            part = part.detach().to(handoff.device).contiguous()
+        if handoff.backend == "gloo":
+            parts = [torch.empty(shape, dtype=dtype) for _ in range(W)]
+            dist.all_gather(parts, part, group=handoff.group)
+        else:
+            both = torch.empty((W,) + shape, dtype=dtype, device=handoff.device)
+            dist.all_gather_into_tensor(both, part, group=handoff.group)
+            parts = list(both.unbind(0))
+        if me == 0:
+            for j in range(W):
+                if r * W + j < n_chunks:
+                    out[r * W + j] = parts[j]
+    return out if me == 0 else None
+
+
+_DTYPES = [torch.float32, torch.bfloat16, torch.float16, torch.uint8, torch.int64, torch.int32, torch.float64]

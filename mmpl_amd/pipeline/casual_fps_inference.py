@@ -96,9 +96,13 @@ class CausalFPSInferencePipeline(torch.nn.Module):
             self._forward(latents, d, timestep * 0, kv, cross, frames)
 
     def inference(self, noise: torch.Tensor, text_prompts: List[str], initial_latent: Optional[torch.Tensor] = None,
-                  return_latents: bool = False, start_frame_index: Optional[int] = 0, decode: bool = True):
+                  return_latents: bool = False, start_frame_index: Optional[int] = 0, decode: bool = True,
+                  image_condition: Optional[dict] = None):
         """noise: [1, 21, 16, h, w]; initial_latent: [1, n, 16, h, w] (T2V chunks >= 2: n = 2; I2V: n = 1 image latent,
-        chunks >= 2: n = 2).  Returns video [1, T, 3, 8h, 8w] in [0, 1] (and the latents)."""
+        chunks >= 2: n = 2).  Returns video [1, T, 3, 8h, 8w] in [0, 1] (and the latents).
+        image_condition: {"clip_fea": [257, 1280], "y": [20, 21, h, w]} (mmpl_amd.i2v_condition.build_image_condition) --
+        required when the generator is the Wan-I2V model type; both CFG branches get the same one, as in
+        wan/image2video.py:283-295 (arg_c / arg_null)."""
         batch_size, num_frames, num_channels, height, width = noise.shape
         assert batch_size == 1 and num_frames == self.geometry.frames_per_chunk
         dev = noise.device
@@ -112,6 +116,15 @@ class CausalFPSInferencePipeline(torch.nn.Module):
             conditional_dict = (self.text_encoder(text_prompts=text_prompts) if pair is None or pair.role == 0 else None)
             unconditional_dict = (self.text_encoder(text_prompts=[self.args.negative_prompt] * len(text_prompts))
                                   if pair is None or pair.role == 1 else None)
+            if getattr(self.generator_cond, "model_type", "t2v") == "i2v":
+                if image_condition is None:
+                    raise ValueError("the Wan-I2V model type needs image_condition = {'clip_fea', 'y'}")
+                ic = {k: image_condition[k].to(device=dev, dtype=torch.bfloat16).contiguous() for k in ("clip_fea", "y")}
+                if pair is not None:                                          # one image per pair: role 0's
+                    ic = {k: pair.broadcast(v) for k, v in ic.items()}
+                for d in (conditional_dict, unconditional_dict):
+                    if d is not None:
+                        d.update(ic)
 
             output = torch.zeros_like(noise)
             want_pos, want_neg = pair is None or pair.role == 0, pair is None or pair.role == 1

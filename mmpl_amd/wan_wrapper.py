@@ -3,7 +3,12 @@
   * ``WanFPSWrapper``   (:317-515)  generator: forward(noisy, conditional_dict, timestep, kv_cache, crossattn_cache,
                                     current_start, cache_start) -> (flow_pred, pred_x0)
   * ``WanVAEWrapper``   (:54-113)   decode_to_pixel / encode_to_latent
-  * ``WanTextEncoder``  (:15-51)    seam only (umT5-xxl is outside this round's hot path)
+  * ``WanTextEncoder``  (:15-51)    tokenizer -> HIP umT5-xxl engine (mmpl_amd/t5.py) -> padding rows zeroed
+
+``WanFPSWrapper`` also serves the Wan-I2V model type (``config.json`` model_type 'i2v', wan/modules/model.py:563-616):
+``forward`` / ``capture`` take ``clip_fea`` and ``y`` (kwargs like ``WanModel.forward``, model.py:626-640, or entries of
+``conditional_dict``), build the image K / V once per ``clip_fea`` and concatenate the stage's frames of ``y`` to the
+latents on the channel axis (model.py:680-681).
 
 KV caches keep the reference's shape of a list of per-layer dicts (``k``, ``v``, ``attention_vis_index`` ...,
 pipeline/casual_fps_inference.py:453-501) so pipeline-style code runs unchanged, but the per-layer tensors are views
@@ -98,6 +103,8 @@ class WanFPSWrapper(torch.nn.Module):
         self.model = _ModelHandle(self.engine)
         if disk_sd is not None:
             self.engine.load_state_dict(disk_sd)
+        self.model_type = self.engine.model_type
+        self._clip_src = None                 # the clip_fea tensor the engine's image K/V were built from
         self.uniform_timestep = not is_causal
         self.scheduler = FlowMatchScheduler(shift=timestep_shift, sigma_min=0.0, extra_one_step=True)
         self.scheduler.set_timesteps(1000, training=True)
@@ -122,7 +129,26 @@ class WanFPSWrapper(torch.nn.Module):
     def new_crossattn_cache(self) -> CrossAttnCache:
         return CrossAttnCache(self.engine)
 
-    def capture(self, noisy_image_or_video, conditional_dict, timestep, kv_cache, crossattn_cache, current_start, out):
+    def _image_stream(self, frames, conditional_dict, clip_fea, y):
+        """Wan-I2V model type: make sure the engine's image K/V belong to this `clip_fea` (MLPProj + per-block k_img / v_img,
+        once per image) and return the stage's slice of the conditioning video, [nF, 20, h, w] bf16 (None for t2v)."""
+        if self.model_type != "i2v":
+            return None
+        clip_fea = conditional_dict.get("clip_fea") if clip_fea is None else clip_fea
+        y = conditional_dict.get("y") if y is None else y
+        if clip_fea is None or y is None:
+            raise ValueError("WanFPSWrapper: an i2v model needs clip_fea and y (model.py:672-673)")
+        if clip_fea is not self._clip_src:
+            fea = clip_fea[0] if clip_fea.dim() == 3 else clip_fea
+            self.engine.set_image_kv(*self.engine.precompute_image_context(fea))
+            self._clip_src = clip_fea
+        yy = y[0] if isinstance(y, (list, tuple)) or y.dim() == 5 else y              # [20, F, h, w]
+        assert yy.shape[0] == self.engine.in_dim - 16 and yy.shape[2:] == (self.engine.lat_h, self.engine.lat_w), tuple(yy.shape)
+        # (a stack of views: no host-built index tensor, so this also runs inside a hipGraph capture)
+        return torch.stack([yy[:, f] for f in frames], dim=0).to(device=self.engine.device, dtype=torch.bfloat16)
+
+    def capture(self, noisy_image_or_video, conditional_dict, timestep, kv_cache, crossattn_cache, current_start, out,
+                clip_fea=None, y=None):
         """hipGraph of this exact forward (fixed buffers / stage shape); returns the graph, replay() re-runs it on the
         current contents of `noisy_image_or_video`, `timestep` and the caches."""
         assert noisy_image_or_video.is_contiguous() and noisy_image_or_video.dtype == torch.bfloat16
@@ -138,14 +164,19 @@ class WanFPSWrapper(torch.nn.Module):
             for s in starts:
                 if s not in vis:
                     vis.append(s)
-        return self.engine.capture(noisy_image_or_video[0], timestep.view(-1), frames, StagePlan.write_slots(frames),
+        x, pre = noisy_image_or_video[0], None
+        ys = self._image_stream(frames, conditional_dict, clip_fea, y)
+        if ys is not None:                    # static 36-channel input; the graph refreshes its latent channels before the forward
+            lat, x = x, torch.cat([x, ys], dim=1).contiguous()
+            pre = lambda: x[:, :16].copy_(lat)
+        return self.engine.capture(x, timestep.view(-1), frames, StagePlan.write_slots(frames),
                                    [slot_of(o // S) for o in vis], kv_cache.k_all, kv_cache.v_all, crossattn_cache.k_all,
-                                   crossattn_cache.v_all, out[0])
+                                   crossattn_cache.v_all, out[0], pre=pre)
 
     def forward(self, noisy_image_or_video: torch.Tensor, conditional_dict: dict, timestep: torch.Tensor,
                 kv_cache: Optional[KVCache] = None, crossattn_cache: Optional[CrossAttnCache] = None,
                 current_start=None, classify_mode=False, concat_time_embeddings=False, clean_x=None, aug_t=None,
-                cache_start=None, out: Optional[torch.Tensor] = None, return_x0: bool = False):
+                cache_start=None, out: Optional[torch.Tensor] = None, return_x0: bool = False, clip_fea=None, y=None):
         assert kv_cache is not None and crossattn_cache is not None, "the FPS path always runs with caches"
         assert noisy_image_or_video.shape[0] == 1, "batch size 1 (as every reference entry point)"
         S = self.engine.S
@@ -162,17 +193,21 @@ class WanFPSWrapper(torch.nn.Module):
         x = noisy_image_or_video[0]
         if x.dtype != torch.bfloat16 or not x.is_contiguous():
             x = x.to(torch.bfloat16).contiguous()
+        lat = x
+        ys = self._image_stream(frames, conditional_dict, clip_fea, y)
+        if ys is not None:
+            x = torch.cat([x, ys], dim=1).contiguous()                     # model.py:680-681
         t = timestep.reshape(-1).to(device=x.device, dtype=torch.float32)
-        y = self.engine.forward(x, t, frames, StagePlan.write_slots(frames), [slot_of(o // S) for o in vis],
-                                kv_cache.k_all, kv_cache.v_all, crossattn_cache.k_all, crossattn_cache.v_all,
-                                out=None if out is None else out[0])
-        flow_pred = y.unsqueeze(0)
+        flow = self.engine.forward(x, t, frames, StagePlan.write_slots(frames), [slot_of(o // S) for o in vis],
+                                   kv_cache.k_all, kv_cache.v_all, crossattn_cache.k_all, crossattn_cache.v_all,
+                                   out=None if out is None else out[0])
+        flow_pred = flow.unsqueeze(0)
         pred_x0 = None
         if return_x0:                                                     # wan_wrapper.py:373-397 (unused by the pipeline)
             sig = self.scheduler.sigmas.double().to(x.device)
             ts = self.scheduler.timesteps.double().to(x.device)
             tid = torch.argmin((ts.unsqueeze(0) - t.double().unsqueeze(1)).abs(), dim=1)
-            pred_x0 = (x.double() - sig[tid].reshape(-1, 1, 1, 1) * y.double()).to(y.dtype).unsqueeze(0)
+            pred_x0 = (lat.double() - sig[tid].reshape(-1, 1, 1, 1) * flow.double()).to(flow.dtype).unsqueeze(0)
         return flow_pred, pred_x0
 
 

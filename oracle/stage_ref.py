@@ -73,9 +73,12 @@ def run_chunk(p: Dict[str, torch.Tensor], cfg: W.DitCfg, noise: torch.Tensor, ct
               ctx_uncond: torch.Tensor, renoise: Optional[Dict[int, torch.Tensor]] = None,
               initial_latent: Optional[torch.Tensor] = None, mode: str = "t2v", guidance: float = 5.0,
               steps: int = 50, shift: float = 5.0, attn_fn=W.sdpa, trace: Optional[list] = None,
-              gpu_scalar_semantics: bool = False):
+              gpu_scalar_semantics: bool = False, clip_fea: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None):
     """noise: [1, 21, 16, h, w]; renoise: {frame: [1,16,h,w]} replacements for frames 4,9,13,18 (t2v only);
-    initial_latent: [1, 2, 16, h, w] or None.  Returns (output latents [1,21,16,h,w], hand-off tensor)."""
+    initial_latent: [1, 2, 16, h, w] or None.  Returns (output latents [1,21,16,h,w], hand-off tensor).
+    clip_fea [257, clip_dim] and y [20, 21, h, w]: the Wan-I2V model type (p holds img_emb / k_img / v_img, cfg.in_dim 36) --
+    every forward sees its frames of y concatenated to the latents on the channel axis (wan/modules/model.py:680-681) and
+    both CFG branches share clip_fea and y (wan/image2video.py:283-295)."""
     clean = T2V_CLEAN_STEPS if mode == "t2v" else I2V_CLEAN_STEPS
     stages = stage_frames(clean)
     S = (noise.shape[-2] // 2) * (noise.shape[-1] // 2)
@@ -89,9 +92,12 @@ def run_chunk(p: Dict[str, torch.Tensor], cfg: W.DitCfg, noise: torch.Tensor, ct
     def fwd(which, lat, tval, frames):
         vis[which].on_forward(frames)
         t = torch.full([1, len(frames)], float(tval), dtype=torch.float32)
-        y = W.dit_forward(p, cfg, lat[0].permute(1, 0, 2, 3), t, ctxs[which], caches[which], cross[which], frames,
-                          write_slots_for(frames), vis[which].slots(), attn_fn)
-        return y.permute(1, 0, 2, 3).unsqueeze(0)
+        x = lat[0].permute(1, 0, 2, 3)
+        if y is not None:
+            x = torch.cat([x, y[:, frames].to(x.dtype)], dim=0)
+        o = W.dit_forward(p, cfg, x, t, ctxs[which], caches[which], cross[which], frames,
+                          write_slots_for(frames), vis[which].slots(), attn_fn, clip_fea=clip_fea)
+        return o.permute(1, 0, 2, 3).unsqueeze(0)
 
     def refresh(lat, frames):
         for which in (0, 1):

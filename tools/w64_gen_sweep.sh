@@ -11,7 +11,11 @@ for cfg in "$@"; do
     python -m mmpl_amd.build > /dev/null 2>&1
     timeout 300 python tools/attn_dev.py check 4 2>&1 | tail -3 >> $out
   fi
+  # (build.py keys staleness on the flags too: switching to / from the timing build always recompiles)
   MMPL_EXTRA_HIPCC_FLAGS="-DW64_ABL=16" python -m mmpl_amd.build > /dev/null 2>&1
   timeout 200 python tools/attn_dev.py cycles 2>&1 | grep cycles >> $out
 done
+# restore: the committed default schedule and a clean library (the timing build's attention outputs are cycle counts, not O)
+python tools/gen_attn_w64.py > /dev/null 2>&1
+python -m mmpl_amd.build > /dev/null 2>&1
 cat $out
