@@ -430,6 +430,10 @@ MMPL_DEV void gemm_epilogue_staged(const GemmArgs& g, const f32x4 (&acc)[2][4][4
   }
 }
 
+#ifndef GEMM6_ABL
+#define GEMM6_ABL 0         // dev ablations (results are garbage): 1 = every block's LDS-DMA reads operand tile (0, 0): same instruction
+#endif                      // stream and LDS traffic, every fetch an L2 hit -> what the loop costs without fabric / HBM latency;
+                            // 2 = no epilogue at all (what a perfectly overlapped epilogue would leave); 4 = no LDS-DMA in the k loop
 #ifndef GEMM6_TIMING
 #define GEMM6_TIMING 0      // dev: 1 = every wave leaves { prologue, k loop, epilogue } shader cycles over the output (tools/bench_kernels.py gemmphases)
 #endif
@@ -487,7 +491,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto issue_piece = [&](int q, char* st) {
     const bool isw = q >= 8;
     const int p = 4 * (q & 7) + wave;                              // piece of the A (or W) tile: rows 8p .. 8p+7
-    const int row = isw ? min(n0 + 8 * p + lr, g.N - 1) : min(m0 + 8 * p + lr, g.M - 1);
+    int row = isw ? min(n0 + 8 * p + lr, g.N - 1) : min(m0 + 8 * p + lr, g.M - 1);
+    if constexpr (GEMM6_ABL & 1) row = 8 * p + lr;
     const uint32_t voff = (uint32_t)(row * (isw ? g.ldw : g.lda) + lc) * 2u;
     glds16s(isw ? w_k : a_k, voff, st + (isw ? A4_BYTES : 0) + p * 1024);
   };
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // =========================== R_t
     const char* st = smem + (t & 1) * STAGE4;
     char* nx = smem + ((t + 1) & 1) * STAGE4;
-    const bool do_issue = grp == 0 && t + 1 < nt;
+    const bool do_issue = grp == 0 && t + 1 < nt && !(GEMM6_ABL & 4);
     bf16x8 af[2][8], wf[2][4];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -564,7 +569,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (grp == 0 || t + 1 < nt) __builtin_amdgcn_s_barrier();
   }
   if constexpr (GEMM6_TIMING) tk2 = __builtin_readcyclecounter();
-  if (EPI != EPI_F32_SCALE && g.staged_epilogue) {
+  if constexpr (GEMM6_ABL & 2) {
+    if (g.M < 0) gemm_epilogue<EPI>(g, acc[0], m0 + 128 * wm, n0 + 64 * wn, frow, fchunk);      // keeps the accumulators alive
+  } else if (EPI != EPI_F32_SCALE && g.staged_epilogue) {
     gemm_epilogue_staged<EPI>(g, acc, smem + wave * (128 * 128), m0 + 128 * wm, n0 + 64 * wn, lane);
   } else {
     gemm_epilogue<EPI>(g, acc[0], m0 + 128 * wm, n0 + 64 * wn, frow, fchunk);

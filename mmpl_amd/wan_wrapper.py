@@ -73,6 +73,17 @@ class CrossAttnCache(list):
             b["is_init"] = True
 
 
+class _HeldGraph:
+    """A hipGraph together with the buffers it captured BY ADDRESS that nobody else owns (the i2v model type's 36-channel input:
+    allocated outside the capture, so it would go back to the allocator -- and be overwritten -- once capture() returns)."""
+
+    def __init__(self, graph, *keep):
+        self.graph, self.keep = graph, keep
+
+    def replay(self):
+        self.graph.replay()
+
+
 class _ModelHandle:
     """What the pipeline touches on `generator.model` (num_frame_per_block, parameters())."""
 
@@ -169,9 +180,10 @@ class WanFPSWrapper(torch.nn.Module):
         if ys is not None:                    # static 36-channel input; the graph refreshes its latent channels before the forward
             lat, x = x, torch.cat([x, ys], dim=1).contiguous()
             pre = lambda: x[:, :16].copy_(lat)
-        return self.engine.capture(x, timestep.view(-1), frames, StagePlan.write_slots(frames),
-                                   [slot_of(o // S) for o in vis], kv_cache.k_all, kv_cache.v_all, crossattn_cache.k_all,
-                                   crossattn_cache.v_all, out[0], pre=pre)
+        g = self.engine.capture(x, timestep.view(-1), frames, StagePlan.write_slots(frames),
+                                [slot_of(o // S) for o in vis], kv_cache.k_all, kv_cache.v_all, crossattn_cache.k_all,
+                                crossattn_cache.v_all, out[0], pre=pre)
+        return g if ys is None else _HeldGraph(g, x)
 
     def forward(self, noisy_image_or_video: torch.Tensor, conditional_dict: dict, timestep: torch.Tensor,
                 kv_cache: Optional[KVCache] = None, crossattn_cache: Optional[CrossAttnCache] = None,

@@ -71,6 +71,19 @@ def bench_gemm(iters):
               f"{2.0 * M * N * K / ms_t / 1e9:8.1f} TFLOP/s", flush=True)
 
 
+def bench_gemm_ref(iters):
+    """yardstick only (never on the product path): the vendor library (torch.matmul -> hipBLASLt / rocBLAS) on the same shapes
+    and the same random operands, plain C = A W^T without bias / epilogue"""
+    for name, M, N, K in (("qkv", 25200, 15360, 5120), ("o", 25200, 5120, 5120), ("ffn0", 25200, 13824, 5120), ("ffn2", 25200, 5120, 13824),
+                          ("qkv_s0", 7200, 15360, 5120), ("sq8k", 8192, 8192, 8192)):
+        A = torch.randn(M, K, device=dev).to(BF)
+        W = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(BF)
+        out = torch.empty(M, N, device=dev, dtype=BF)
+        fn = lambda: torch.matmul(A, W.t(), out=out)
+        ms = min(timeit(fn, iters), timeit(fn, iters))
+        print(f"vendor gemm {name}: M={M} N={N} K={K}  {ms:8.3f} ms  {2.0 * M * N * K / ms / 1e9:8.1f} TFLOP/s", flush=True)
+
+
 def gemm_phases(epi=3):
     """needs a -DGEMM_ABL=32 build: per-wave { prologue, k loop, epilogue } cycles written over the output"""
     M, N, K = 25200, 5120, 5120
@@ -121,3 +134,5 @@ if __name__ == "__main__":
         gemm_phases(0)
     if what in ("gemm", "all"):
         bench_gemm(iters)
+    if what == "gemmref":
+        bench_gemm_ref(iters)
