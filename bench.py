@@ -474,6 +474,14 @@ def main():
             if "gemm" in prof:
                 g = prof["gemm"]
                 res["gemm_tflops"] = g["flops"] / (g["ms"] * 1e-3) / 1e12
+        if isinstance(vae_s, float):
+            # hook-counted conv + attention FLOPs of the reference decoder (vae.py:545-569), 10.54 TFLOP for the first
+            # latent frame + 31.77 TFLOP per further one at 720p (90 x 160 latents), proportional to h * w
+            vfl = (10.54e12 + 20 * 31.77e12) * (lat_h * lat_w) / (90.0 * 160.0)
+            res["vae_roofline"] = {"bound": "mfma", "kernel": "mmpl_vae_decode (21 latent -> 81 pixel frames; implicit-GEMM causal conv3d / conv2d + fused norm / upsample kernels)",
+                                   "achieved": vfl / vae_s / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": vfl / vae_s / 1e12 / MFMA_PEAK_TFLOPS, "algorithmic_flops": vfl, "seconds": vae_s,
+                                   "note": "reported beside the DiT metric, not part of `value` (0.35 % of a chunk)"}
         if not args.no_cpu_baseline and world == 1:
             try:
                 res["cpu_baseline"] = cpu_baseline(cfg, lat_h, lat_w, stage_shapes, args.cpu_budget_s)

@@ -352,6 +352,36 @@ MMPL_DEV void glds16s(const void* base, uint32_t voff, char* lds) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(dst) : "memory");
 }
 
+#ifndef GEMM6_ABL
+#define GEMM6_ABL 0         // dev ablations (results are garbage): 1 = every block's LDS-DMA reads operand tile (0, 0): same instruction
+#endif                      // stream and LDS traffic, every fetch an L2 hit -> what the loop costs without fabric / HBM latency;
+                            // 2 = no epilogue at all (what a perfectly overlapped epilogue would leave); 4 = no LDS-DMA in the k loop;
+                            // 8 = the whole staged epilogue except its global stores
+#ifndef GEMM6_STORE
+#define GEMM6_STORE 1       // cache policy of the staged epilogue's C stores: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1 (write-through, no L2 allocate)
+#endif
+#ifndef GEMM6_RESLD
+#define GEMM6_RESLD 0       // residual loads of the staged epilogue: 0 plain, 1 nt
+#endif
+MMPL_DEV void store16_c(void* p, const uint4& v) {
+  const u32x4 w = {v.x, v.y, v.z, v.w};
+#if GEMM6_STORE == 1
+  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
+#elif GEMM6_STORE == 2
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
+#elif GEMM6_STORE == 3
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
+#else
+  *reinterpret_cast<u32x4*>(p) = w;
+#endif
+}
+// L2 prefetch of one 64-byte half line per lane: an LDS-DMA dword into a dump area nobody reads (no destination VGPR, nothing to
+// wait for in the loop; the issuing wave drains vmcnt before it leaves the kernel)
+MMPL_DEV void glds4s(const void* base, uint32_t voff, char* lds) {
+  const uint32_t dst = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)lds);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(base), "s"(dst) : "memory");
+}
+
 // v6 epilogue, LDS-staged.  The MFMA leaves each lane with one token row and 4 consecutive output columns per fragment: stored
 // directly that is 8 bytes per lane into 64 different rows per instruction.  Instead: bias, the Linear's bf16 rounding and the
 // activation happen on the MFMA side, the wave's 128 x 64 sub-tile goes to its 16 KiB of the (now idle) LDS ring as bf16
@@ -369,8 +399,24 @@ MMPL_DEV void gemm_epilogue_staged(const GemmArgs& g, const f32x4 (&acc)[2][4][4
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int m = mw + 8 * u + erow;
-      res8[u] = (n_ok && m < g.M) ? *reinterpret_cast<const uint4*>(g.res + (size_t)m * g.ldres + n) : uint4{0u, 0u, 0u, 0u};
+      if (n_ok && m < g.M) {
+        const u32x4* rp = reinterpret_cast<const u32x4*>(g.res + (size_t)m * g.ldres + n);
+        const u32x4 rv = GEMM6_RESLD ? __builtin_nontemporal_load(rp) : *rp;
+        res8[u] = uint4{rv[0], rv[1], rv[2], rv[3]};
+      } else {
+        res8[u] = uint4{0u, 0u, 0u, 0u};
+      }
     }
+  }
+  // the gate is a per-FRAME vector: the sub-tile's 128 rows touch at most two frames (rows_per_frame >= 128 on this path, launcher),
+  // so its two candidate rows are fetched once, beside the residual, instead of one dependent L2 round trip per row step
+  uint4 gate_lo = uint4{0u, 0u, 0u, 0u}, gate_hi = gate_lo;
+  int f_lo = 0;
+  if (EPI == EPI_GATE_RES && n_ok) {
+    f_lo = min(mw, g.M - 1) / g.rows_per_frame;
+    const int f_hi = min(mw + 127, g.M - 1) / g.rows_per_frame;
+    gate_lo = *reinterpret_cast<const uint4*>(g.gate + (size_t)f_lo * g.gate_frame_stride + n);
+    gate_hi = *reinterpret_cast<const uint4*>(g.gate + (size_t)f_hi * g.gate_frame_stride + n);
   }
   uint2 bias4[4];
 #pragma unroll
@@ -409,7 +455,7 @@ MMPL_DEV void gemm_epilogue_staged(const GemmArgs& g, const f32x4 (&acc)[2][4][4
     uint4 ov = yv;
     if (HAS_RES) {
       uint4 ev = uint4{0u, 0u, 0u, 0u};
-      if (EPI == EPI_GATE_RES) ev = *reinterpret_cast<const uint4*>(g.gate + (size_t)(m / g.rows_per_frame) * g.gate_frame_stride + n);
+      if (EPI == EPI_GATE_RES) ev = (m / g.rows_per_frame == f_lo) ? gate_lo : gate_hi;
       const uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w}, xw[4] = {res8[u].x, res8[u].y, res8[u].z, res8[u].w}, ew[4] = {ev.x, ev.y, ev.z, ev.w};
       float v[8];
 #pragma unroll
@@ -421,19 +467,16 @@ MMPL_DEV void gemm_epilogue_staged(const GemmArgs& g, const f32x4 (&acc)[2][4][4
       }
       ov.x = pack2bf(v[0], v[1]); ov.y = pack2bf(v[2], v[3]); ov.z = pack2bf(v[4], v[5]); ov.w = pack2bf(v[6], v[7]);
     }
+    if ((GEMM6_ABL & 8) && g.M >= 0) { asm volatile("" ::"v"(ov.x), "v"(ov.y), "v"(ov.z), "v"(ov.w)); continue; }
     if (EPI == EPI_BIAS_VPAGES && n >= g.v_col0) {
       const int fr = m / g.rows_per_frame;
-      *reinterpret_cast<uint4*>(g.v_dst[fr] + (size_t)(m - fr * g.rows_per_frame) * g.v_ld + (n - g.v_col0)) = ov;
+      store16_c(g.v_dst[fr] + (size_t)(m - fr * g.rows_per_frame) * g.v_ld + (n - g.v_col0), ov);
     } else {
-      *reinterpret_cast<uint4*>(g.C + (size_t)m * g.ldc + n) = ov;
+      store16_c(g.C + (size_t)m * g.ldc + n, ov);
     }
   }
 }
 
-#ifndef GEMM6_ABL
-#define GEMM6_ABL 0         // dev ablations (results are garbage): 1 = every block's LDS-DMA reads operand tile (0, 0): same instruction
-#endif                      // stream and LDS traffic, every fetch an L2 hit -> what the loop costs without fabric / HBM latency;
-                            // 2 = no epilogue at all (what a perfectly overlapped epilogue would leave); 4 = no LDS-DMA in the k loop
 #ifndef GEMM6_TIMING
 #define GEMM6_TIMING 0      // dev: 1 = every wave leaves { prologue, k loop, epilogue } shader cycles over the output (tools/bench_kernels.py gemmphases)
 #endif
@@ -444,21 +487,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if constexpr (GEMM6_TIMING) tk0 = __builtin_readcyclecounter();
   const int tiles_m = (g.M + BM3 - 1) / BM3, tiles_n = (g.N + BN3 - 1) / BN3;
   const int nwg = tiles_m * tiles_n;
-  // Tile order: XCD x owns the x-th contiguous chunk of the grouped-M tile list (q + 1 tiles for x < r, else q), so that the
-  // blocks sharing one L2 work on neighbouring tiles.  Without a tile counter block b IS tile b (the hardware deals blocks
-  // round-robin to the XCDs).  With one (g.tile_counter) the kernel is launched once per CU and a block takes the next tile of
-  // ITS XCD's chunk when it is done with the previous one: equal tiles do not take equal time (blocks that are first to touch an
+  // Tile order: every XCD owns a list of tiles in grouped-M order (below), so that the blocks sharing one L2 work on neighbouring
+  // tiles.  Without a tile counter block b is entry b >> 3 of XCD b & 7's list (the hardware deals blocks round-robin to the
+  // XCDs).  With one (g.tile_counter) the kernel is launched once per CU and a block takes the next tile of ITS XCD's list when
+  // it is done with the previous one: equal tiles do not take equal time (blocks that are first to touch an
   // operand panel wait on HBM, 33-42 cycles per MFMA across blocks), and a lock-step round lasts as long as its slowest block.
   // Ticket protocol: exactly chunk + (blocks of the XCD) tickets are drawn per launch; whoever draws the last one knows every
   // other block of the XCD is leaving and zeroes the counter for the next launch.
   __shared__ int s_ticket;
   const bool persistent = g.tile_counter != nullptr;
   const int my_xcd = blockIdx.x & 7;
-  const int chunk = (nwg >> 3) + (my_xcd < (nwg & 7) ? 1 : 0);
+  const int GROUP = g.group;
+  const int per_group = GROUP * tiles_n;
+  // Sweep-synchronous order (g.sync_sweeps): the M-groups (GROUP row panels x all column panels) are dealt to the XCDs like cards
+  // -- XCD x works through groups x, x + 8, x + 16, ... -- so all eight XCDs walk the column panels of W at the same time, a W
+  // panel comes out of HBM once per sweep and the other seven XCDs find it in the Infinity Cache.  With contiguous chunks of
+  // the tile list (the previous order) the XCDs sat at eight different column positions and W was streamed from HBM eight
+  // times over: 8.5 GB of fabric reads per qkv GEMM, 2.7 TB/s, every L2 miss an HBM miss.  What the deal leaves over (fewer than
+  // 8 full groups, a ragged last group) is split into eight contiguous chunks as before.
+  const int full_groups = tiles_m / GROUP;
+  const int rounds = g.sync_sweeps ? full_groups >> 3 : 0;
+  const int dealt = rounds * per_group;                              // tiles per XCD that come from dealt groups
+  const int left = nwg - 8 * dealt;                                  // tiles of the remainder list
+  const int lq = left >> 3, lr = left & 7;
+  const int chunk = dealt + lq + (my_xcd < lr ? 1 : 0);
   const int blocks_x = (int)(gridDim.x >> 3) + (my_xcd < (int)(gridDim.x & 7) ? 1 : 0);
   for (;;) {
-  int bid = blockIdx.x;
-  if (persistent) {
+  int idx = blockIdx.x >> 3;                                         // index into THIS XCD's tile list (block b of a one-block-per-tile
+  if (persistent) {                                                  // launch runs on XCD b & 7: the hardware deals blocks round-robin)
     if (threadIdx.x == 0) s_ticket = atomicAdd(g.tile_counter + my_xcd, 1);
     __syncthreads();
     const int ticket = s_ticket;
@@ -466,14 +522,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (ticket == chunk + blocks_x - 1 && threadIdx.x == 0) g.tile_counter[my_xcd] = 0;
       return;
     }
-    bid = ticket * 8 + my_xcd;
+    idx = ticket;
   }
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  int bid;                                                           // position in the grouped-M tile list
+  if (idx < dealt) {
+    bid = ((idx / per_group) * 8 + my_xcd) * per_group + idx % per_group;
+  } else {
+    bid = 8 * dealt + (my_xcd < lr ? my_xcd * (lq + 1) : lr * (lq + 1) + (my_xcd - lr) * lq) + (idx - dealt);
   }
-  const int GROUP = g.group;
-  const int per_group = GROUP * tiles_n;
   const int gid = bid / per_group;
   const int first_m = gid * GROUP;
   const int gsz = min(tiles_m - first_m, GROUP);
@@ -485,14 +541,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int wm = wave >> 2, wn = wave & 3, grp = wave >> 2;
 
   // ---- DMA (group A only): wave w issues pieces 4q + w, q = 0..15 (q < 8: A rows 8*(4q+w).., q >= 8: W rows)
-  const int lr = lane >> 3, lc = ((lane & 7) ^ (lr & 7)) << 3;     // row within the piece, swizzled source chunk (elements)
+  const int prow = lane >> 3, lc = ((lane & 7) ^ (prow & 7)) << 3;   // row within the piece, swizzled source chunk (elements)
   const bf16_t* a_k = g.A;                                         // advance by BK4 elements per tile
   const bf16_t* w_k = g.W;
   auto issue_piece = [&](int q, char* st) {
     const bool isw = q >= 8;
     const int p = 4 * (q & 7) + wave;                              // piece of the A (or W) tile: rows 8p .. 8p+7
-    int row = isw ? min(n0 + 8 * p + lr, g.N - 1) : min(m0 + 8 * p + lr, g.M - 1);
-    if constexpr (GEMM6_ABL & 1) row = 8 * p + lr;
+    int row = isw ? min(n0 + 8 * p + prow, g.N - 1) : min(m0 + 8 * p + prow, g.M - 1);
+    if constexpr (GEMM6_ABL & 1) row = 8 * p + prow;
     const uint32_t voff = (uint32_t)(row * (isw ? g.ldw : g.lda) + lc) * 2u;
     glds16s(isw ? w_k : a_k, voff, st + (isw ? A4_BYTES : 0) + p * 1024);
   };
@@ -511,6 +567,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
   for (int i = 0; i < 4; ++i) w_off[i] = A4_BYTES + swz64(64 * wn + 16 * i + frow, fchunk);
   const int nt = g.K / BK4;
+  // L2 prefetch shares (see the loop): wave-uniform scalars
+  const bool pf_on = g.pf_dist > 0 && grp == 1 && gsz >= 2;
+  const int pf_P = 32 / gsz;
+  const int pf_nw = __builtin_amdgcn_readfirstlane(2 * (256 / gsz)), pf_na = __builtin_amdgcn_readfirstlane(2 * (256 / pf_P));
+  const int pf_wrow0 = __builtin_amdgcn_readfirstlane(n0 + ((bid % per_group) % gsz) * (256 / gsz));
+  const int pf_arow0 = __builtin_amdgcn_readfirstlane(m0 + (tn % pf_P) * (256 / pf_P));
 
   if (grp == 0) {
 #pragma unroll
@@ -525,6 +587,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   for (int t = 0; t < nt; ++t) {
     // =========================== R_t
+    // L2 prefetch (g.pf_dist k-tiles ahead, group B: its vmcnt has no waiter in the loop; issued at the top of R_t, where the
+    // fragment registers are dead).  The tiles in flight on an XCD share their operand slices -- the gsz tiles of one column panel
+    // its W slice, the ~32 / gsz tiles of one row panel its A slice -- and run in near lock step, so every k-tile somebody takes
+    // the fabric / HBM miss and the sharers queue behind it (with every fetch an L2 hit the same loop runs 10-20 % faster,
+    // GEMM6_ABL=1).  Each tile therefore touches ITS share of both slices early: rows tm_l * 256 / gsz ... of W and
+    // (tn % P) * 256 / P ... of A (P = 32 / gsz), two half lines (64 B) a row, one per lane.
+    if (pf_on && t + g.pf_dist < nt) {
+      const int l = (wave - 4) * 64 + lane;
+      char* dump = smem + 2 * STAGE4 + (wave - 4) * 256;
+      const size_t koff = (size_t)(t + g.pf_dist) * BK4;
+      if (l < pf_nw) glds4s(g.W + koff, (uint32_t)(min(pf_wrow0 + (l >> 1), g.N - 1) * g.ldw + (l & 1) * 32) * 2u, dump);
+      if (l < pf_na) glds4s(g.A + koff, (uint32_t)(min(pf_arow0 + (l >> 1), g.M - 1) * g.lda + (l & 1) * 32) * 2u, dump);
+    }
     const char* st = smem + (t & 1) * STAGE4;
     char* nx = smem + ((t + 1) & 1) * STAGE4;
     const bool do_issue = grp == 0 && t + 1 < nt && !(GEMM6_ABL & 4);
@@ -589,6 +664,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       tp[3] = (float)(2 * nt);                                // in 32-wide k stages, like gemm_w64
     }
   }
+  if (g.pf_dist > 0 && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // prefetch DMAs target this block's LDS
   if (!persistent) return;
   __syncthreads();                 // the ring (and s_ticket) are free again: every wave is done with its epilogue's staging
   }
@@ -596,7 +672,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 template <int EPI>
 hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
-  constexpr int smem = 2 * STAGE4;
+  constexpr int smem = 2 * STAGE4 + 1024;        // ring + the L2 prefetch's dump area
   if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v6_kernel<EPI>), smem); e != hipSuccess) return e;
   const int tiles = ((g.M + BM3 - 1) / BM3) * ((g.N + BN3 - 1) / BN3);
   GemmArgs g2 = g;
@@ -607,9 +683,23 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
   g2.group = env_group > 0 ? env_group : (g.M >= 16384 ? (g.N >= 8192 ? 2 : 3) : 4);
   // the 16-byte epilogue needs 8-element alignment of everything it touches; otherwise the direct 8-byte one
   static const bool env_direct = getenv("MMPL_GEMM_DIRECT_EPILOGUE") != nullptr;
-  g2.staged_epilogue = !env_direct && g.N % 8 == 0 && g.ldc % 8 == 0 && (g.epi != EPI_GATE_RES || g.gate_frame_stride % 8 == 0) &&
+  // (strides AND base pointers: mmpl_gemm is public ABI and callers hand in views such as a column-offset C)
+  auto al = [](const void* p, uintptr_t a) { return p == nullptr || reinterpret_cast<uintptr_t>(p) % a == 0; };
+  bool ptrs_ok = al(g.C, 16) && al(g.bias, 8);
+  if (g.epi == EPI_GATE_RES || g.epi == EPI_RES) ptrs_ok = ptrs_ok && al(g.res, 16);
+  if (g.epi == EPI_GATE_RES) ptrs_ok = ptrs_ok && al(g.gate, 16);
+  if (g.epi == EPI_BIAS_VPAGES)
+    for (int i = 0; i < 8; ++i) ptrs_ok = ptrs_ok && al(g.v_dst[i], 16);
+  g2.staged_epilogue = !env_direct && ptrs_ok && g.N % 8 == 0 && g.ldc % 8 == 0 &&
+                       (g.epi != EPI_GATE_RES || (g.gate_frame_stride % 8 == 0 && g.rows_per_frame >= 128)) &&
                        ((g.epi != EPI_GATE_RES && g.epi != EPI_RES) || g.ldres % 8 == 0) &&
                        (g.epi != EPI_BIAS_VPAGES || (g.v_col0 % 8 == 0 && g.v_ld % 8 == 0));
+  // L2 prefetch distance (k-tiles): 2 measured best on the 14B / 720p block shapes (+1 % qkv / o / ffn0, +6 % ffn2 whose A operand is
+  // 700 MB; 1 = no gain, 4 and more lose again); MMPL_GEMM_PF=0 switches it off
+  static const int env_pf = getenv("MMPL_GEMM_PF") ? atoi(getenv("MMPL_GEMM_PF")) : 2;
+  g2.pf_dist = env_pf;
+  static const bool env_nosync = getenv("MMPL_GEMM_NO_SYNC_SWEEPS") != nullptr;
+  g2.sync_sweeps = !env_nosync;
   static const bool env_static = getenv("MMPL_GEMM_STATIC_TILES") != nullptr;
   if (env_static) g2.tile_counter = nullptr;
   const int n_cu = 8 * mmpl_cus_per_xcd();

@@ -110,6 +110,7 @@ int mmpl_i2v_cross_attn(const void* x, int Lq, int dim, const void* wq, const vo
   I2V_TRY(attend(q, ai, (const bf16_t*)k_img, (const bf16_t*)v_img, n_img, Lq, dim, s), "mmpl_i2v_cross_attn: image attention");
   I2V_TRY(attend(q, at, (const bf16_t*)k_txt, (const bf16_t*)v_txt, n_txt, Lq, dim, s), "mmpl_i2v_cross_attn: text attention");
   add_kernel<<<blocks_for((size_t)Lq * dim), 256, 0, s>>>(at, ai, (size_t)Lq * dim);
+  I2V_TRY(hipGetLastError(), "mmpl_i2v_cross_attn: x + img_x");
   I2V_TRY(linear(at, dim, (const bf16_t*)wo, (const bf16_t*)bo, (bf16_t*)out, Lq, dim, s), "mmpl_i2v_cross_attn: o");
   I2V_TRY(hipGetLastError(), "mmpl_i2v_cross_attn");
   return 0;
@@ -158,6 +159,7 @@ int mmpl_clip_visual(const void* patches, int n_patch, int pk, int dim, int mlp_
     I2V_TRY(mmpl_launch_gemm(g, s), "mmpl_clip_visual: patch embedding");
   }
   add_kernel<<<blocks_for((size_t)n * dim), 256, 0, s>>>(x, G[2], (size_t)n * dim);
+  I2V_TRY(hipGetLastError(), "mmpl_clip_visual: + pos_embedding");
   {
     LnArgs l = {x, dim, hbuf, dim, n, dim, eps, nullptr, nullptr, 0, 1, G[3], G[4]};
     I2V_TRY(mmpl_launch_layernorm(l, s), "mmpl_clip_visual: pre_norm");
@@ -183,6 +185,7 @@ int mmpl_clip_visual(const void* patches, int n_patch, int pk, int dim, int mlp_
     I2V_TRY(mmpl_launch_layernorm(l2, s), "mmpl_clip_visual: norm2");
     I2V_TRY(linear(hbuf, dim, W[8], W[9], big, n, mlp_dim, s), "mmpl_clip_visual: mlp.0");
     gelu_erf_kernel<<<blocks_for((size_t)n * mlp_dim), 256, 0, s>>>(big, (size_t)n * mlp_dim);
+    I2V_TRY(hipGetLastError(), "mmpl_clip_visual: gelu");
     {
       GemmArgs g = {big, mlp_dim, W[10], mlp_dim, W[11], x, dim, n, dim, mlp_dim, EPI_RES, x, dim, nullptr, 0, 1, 1.0f, 0, 0, 0, 0, 0};
       I2V_TRY(mmpl_launch_gemm(g, s), "mmpl_clip_visual: mlp.2 + residual");

@@ -33,6 +33,8 @@ struct GemmArgs {
   // once per CU and its blocks take tiles of their XCD's share from these tickets until none is left (gemm.hip); the
   // launches that share a counter must be ordered (one stream).  Null: one block per tile.
   int* tile_counter;
+  int pf_dist;                   // v6: L2 prefetch distance in k-tiles (0 = off; set by the launcher)
+  int sync_sweeps;               // v6: deal whole M-groups to the XCDs so that all of them sweep W's column panels together (set by the launcher)
 };
 hipError_t mmpl_launch_gemm(const GemmArgs& g, hipStream_t s);
 bool mmpl_gemm_w64_accepts(const GemmArgs& g);                      // gemm_w64.hip: the one-wave-per-SIMD kernel for the large linears

@@ -165,7 +165,9 @@ class FlowUniPCMultistepScheduler:
             rows[i] = probe.step_scalars(guidance)
         raw = torch.frombuffer(bytearray(bytes(rows)), dtype=torch.uint8).clone()
         self._table = raw.to(device)
-        self._t_table = torch.tensor([float(t) for t in self.timesteps[self.step_index:]], dtype=torch.float32, device=device)
+        t_host = [float(t) for t in self.timesteps[self.step_index:]]
+        self._t_table = torch.tensor(t_host, dtype=torch.float32, device=device)
+        self._t_first = t_host[0]          # host copy: reset_step_table must not read the device table (a sync inside timed loops)
         self._counter = torch.zeros(1, dtype=torch.int32, device=device)
         self._table_n = n
 
@@ -175,7 +177,7 @@ class FlowUniPCMultistepScheduler:
         if self._state is not None:
             for t in self._state:
                 t.zero_()
-        timestep.fill_(float(self._t_table[0]))
+        timestep.fill_(self._t_first)
 
     def step_cfg_table(self, flow_cond: torch.Tensor, flow_uncond: torch.Tensor, sample: torch.Tensor, timestep: torch.Tensor) -> None:
         """CFG combine + scheduler step with device-resident scalars (capturable: no host value enters the launch);

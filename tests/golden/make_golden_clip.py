@@ -38,7 +38,10 @@ def load_clip_module():
     clip = importlib.util.module_from_spec(spec)
     sys.modules["wan.modules.clip"] = clip
     spec.loader.exec_module(clip)
-    clip.flash_attention = lambda q, k, v, dropout_p=0.0, causal=False, version=None: attention.attention(q, k, v, dropout_p=dropout_p, causal=causal)
+    # the reference's flash_attention keeps half-precision inputs in THEIR dtype (attention.py:68-75: only non-half inputs are
+    # cast); its SDPA fallback would force bf16, so the dtype is passed through explicitly
+    clip.flash_attention = lambda q, k, v, dropout_p=0.0, causal=False, version=None: attention.attention(q, k, v, dropout_p=dropout_p, causal=causal,
+                                                                                                          dtype=q.dtype)
     return clip
 
 
@@ -63,7 +66,21 @@ def main():
     out = vit(x, use_31_block=True)
     o = clip_ref.clip_visual(sd, x, m["num_heads"], m["num_layers"], m["patch_size"])
     print("[clip] out", tuple(out.shape), "rms", out.float().pow(2).mean().sqrt().item(), "oracle-vs-ref max|d|", (o.float() - out.float()).abs().max().item())
-    torch.save(dict(out=out.clone(), meta=m), os.path.join(HERE, "clip_visual_tiny.pt"))
+    # The dtype Wan-I2V really runs the tower in: fp16 weights under fp16 autocast (clip.py:509-511,540; wan_i2v_14B.py:17
+    # clip_dtype = torch.float16), LayerNorm in fp32.  Same bf16-valued weights cast to fp16 (exact: bf16 -> fp16 only loses range),
+    # same pixels: the distance of the bf16 product path to THIS output is the deviation the fixture above cannot show.
+    vit16 = clip.VisionTransformer(image_size=m["image_size"], patch_size=m["patch_size"], dim=m["dim"], mlp_ratio=4, out_dim=64,
+                                   num_heads=m["num_heads"], num_layers=m["num_layers"], pool_type="token", pre_norm=True, post_norm=False,
+                                   activation="gelu", norm_eps=1e-5).eval()
+    vit16.load_state_dict(sd, strict=False)
+    vit16 = vit16.to(torch.float16)
+    for mod in vit16.modules():
+        if isinstance(mod, torch.nn.LayerNorm):
+            mod.float()
+    out16 = vit16(x.to(torch.float16), use_31_block=True)
+    d = (out16.float() - out.float()).norm() / out16.float().norm()
+    print("[clip] fp16 reference: rel_l2(bf16 reference, fp16 reference) =", d.item())
+    torch.save(dict(out=out.clone(), out_fp16=out16.clone(), bf16_vs_fp16=float(d), meta=m), os.path.join(HERE, "clip_visual_tiny.pt"))
 
 
 if __name__ == "__main__":

@@ -4,7 +4,9 @@ the same seeded weights.  At these sizes the CPU oracle needs hours (SURVEY 8d: 
 the SAME oracle code (oracle/wan_dit_ref.py) evaluated by PyTorch on the device (rocBLAS / SDPA in bf16, heads in
 groups so the score matrix stays bounded) -- an implementation that shares nothing with libmmpl_hip.so.  The CPU
 oracle itself is pinned to the reference in tests/test_oracle_golden.py; its device evaluation is tied back to the
-CPU one on the small case below.  Stated tolerance: rel-L2 <= 2e-2 per forward."""
+CPU one on the small case below.  Stated tolerance: rel-L2 <= 1.8e-2 per forward AND <= 1.3 x the value recorded for the
+configuration when the bound was last reviewed (RECORDED below) -- a regression of 30 % fails even while it is still
+inside the absolute bound."""
 import os
 
 os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")     # the checker's torch convolutions: skip MIOpen's exhaustive search
@@ -16,7 +18,13 @@ import torch.nn.functional as F  # noqa: E402
 from tests.util import rel_l2  # noqa: E402
 
 pytestmark = pytest.mark.gpu
-TOL = 2e-2
+TOL = 1.8e-2
+# max over the stage patterns of rel_l2(HIP, oracle on device), measured on MI355X (profiles/r03*_gputests_parity.log)
+RECORDED = {("1.3B", "t2v"): 1.25e-2, ("14B", "t2v"): 1.5e-2, ("14B", "i2v"): 1.5e-2}
+
+
+def _bound(key):
+    return min(TOL, 1.3 * RECORDED[key])
 
 
 def _grouped_sdpa(q, k, v, group=4):
@@ -28,7 +36,7 @@ def _grouped_sdpa(q, k, v, group=4):
     return torch.cat(outs, dim=2).contiguous()
 
 
-def _stages(cfg_name, lat, layers=None, seed=21, mode="t2v"):
+def _stages(cfg_name, lat, layers=None, seed=21, mode="t2v", mutate=None, n_stages=None):
     from mmpl_amd.dit import DitEngine
     from mmpl_amd.synthetic import WAN_CONFIGS, dit_state_dict
     from oracle import stage_ref
@@ -38,6 +46,8 @@ def _stages(cfg_name, lat, layers=None, seed=21, mode="t2v"):
     if layers:
         cfg["num_layers"] = layers
     sd = dit_state_dict(cfg, seed=seed, device=dev)
+    if mutate is not None:
+        mutate(sd, cfg)
     eng = DitEngine(cfg, lat[0], lat[1], dev)
     eng.load_state_dict(sd)
     ocfg = W.DitCfg(**cfg)
@@ -53,7 +63,7 @@ def _stages(cfg_name, lat, layers=None, seed=21, mode="t2v"):
     vis = stage_ref.VisIndex()
     errs = []
     clean = stage_ref.T2V_CLEAN_STEPS if mode == "t2v" else stage_ref.I2V_CLEAN_STEPS
-    for si, frames in enumerate(stage_ref.stage_frames(clean)):
+    for si, frames in enumerate(stage_ref.stage_frames(clean)[:n_stages]):
         if mode == "t2v" and si == 2:      # I2V never hides frames 19, 20 (MMPL_i2v/pipeline/casual_fps_inference.py:253-335)
             vis.hide()
         if mode == "t2v" and si == 3:
@@ -102,7 +112,26 @@ def test_device_evaluated_oracle_equals_cpu_oracle_small():
 def test_full_size_forward_all_stage_patterns(cfg_name, lat):
     errs = _stages(cfg_name, lat)
     print(f"{cfg_name} {lat}: rel_l2(HIP, oracle on device) per stage = " + ", ".join(f"{e:.3e}" for e in errs))
-    assert max(errs) < TOL
+    assert max(errs) < _bound((cfg_name, "t2v"))
+
+
+def test_full_size_forward_heavy_tailed_14B_anchor_stage():
+    """Whole-forward heavy-tail case at 14B / 720p (all 40 layers, stages s0 then s1 = 7 query frames over 9): the statistics real
+    checkpoints have and unit-variance synthetic weights do not -- QK-norm gains x8 (sharp softmax rows: the exp2 FAST pass's
+    overflow / redo path, bf16 q rounding) and 6 massive-activation channels in the residual stream (patch-embedding bias +-60 on
+    6 columns: LayerNorm statistics, GEMM accumulation and the bf16 residual adds all see a 100x dynamic range).  Checker as
+    above.  The oracle's own two executors differ more here too (sharp softmax amplifies a 1-ulp score change), hence the
+    separately stated bound of 3e-2."""
+    def mutate(sd, cfg):
+        for l in range(cfg["num_layers"]):
+            for k in ("self_attn.norm_q.weight", "self_attn.norm_k.weight"):
+                sd[f"blocks.{l}.{k}"] = (sd[f"blocks.{l}.{k}"].float() * 8.0).to(torch.bfloat16)
+        b = sd["patch_embedding.bias"].float()
+        b[[7, 300, 1111, 2049, 3333, 5000]] = torch.tensor([60.0, -60.0, 45.0, -45.0, 60.0, -50.0], device=b.device)
+        sd["patch_embedding.bias"] = b.to(torch.bfloat16)
+    errs = _stages("14B", (90, 160), mutate=mutate, n_stages=2, seed=33)
+    print("14B (90, 160) heavy-tailed (QK gains x8, 6 massive channels): rel_l2(HIP, oracle on device) s0, s1 = " + ", ".join(f"{e:.3e}" for e in errs))
+    assert len(errs) == 2 and max(errs) < 3e-2
 
 
 def test_full_size_forward_i2v_stage_patterns():
@@ -111,7 +140,7 @@ def test_full_size_forward_i2v_stage_patterns():
     (MMPL_i2v/pipeline/casual_fps_inference.py:253-255)."""
     errs = _stages("14B", (90, 160), mode="i2v")
     print("14B (90, 160) i2v: rel_l2(HIP, oracle on device) per stage = " + ", ".join(f"{e:.3e}" for e in errs))
-    assert len(errs) == 5 and max(errs) < TOL
+    assert len(errs) == 5 and max(errs) < _bound(("14B", "i2v"))
 
 
 def test_vae_720p_decode_encode_vs_device_evaluated_oracle():

@@ -109,6 +109,11 @@ def test_clip_vision_tower_vs_reference_golden():
     e = rel_l2(out, fx["out"])
     print(f"CLIP vision tower: rel_l2 vs reference golden = {e:.3e}")
     assert out.shape == fx["out"].shape and e < 2e-2
+    # Wan-I2V runs this tower in fp16 (clip_dtype, wan_i2v_14B.py:17); the engine computes in bf16 like the rest of the path.
+    # Distance to the reference's fp16 output on the same weights / pixels (the reference's own bf16-vs-fp16 distance: 5.8e-3):
+    e16 = rel_l2(out, fx["out_fp16"])
+    print(f"CLIP vision tower: rel_l2 vs the reference run in fp16 = {e16:.3e} (reference bf16 vs fp16: {fx['bf16_vs_fp16']:.3e})")
+    assert e16 < 1.5e-2 and e16 < 2.5 * fx["bf16_vs_fp16"]
 
 
 def test_clip_vision_tower_vit_h_dims_vs_oracle():

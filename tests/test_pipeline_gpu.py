@@ -1,8 +1,9 @@
 """End-to-end: CausalFPSInferencePipeline.inference (HIP) vs the oracle's re-enactment of the reference stage loop,
 including the hand-off tensor, the chunk >= 2 path (initial_latent), I2V mode and the VAE decode (-m gpu).
 
-Trajectory-level tolerance (stated): rel-L2 <= 4e-2 after 4 stages x (2 UniPC steps x 2 CFG forwards + refresh) --
-the reference itself decorrelates by 5.5e-3 on this test when only its K/V gather ORDER changes (tests/golden)."""
+Trajectory-level tolerance (stated): rel-L2 <= 1.5e-2 after 4 stages x (2 UniPC steps x 2 CFG forwards + refresh) --
+measured 5.6-5.9e-3; the reference itself decorrelates by 5.5e-3 on this test when only its K/V gather ORDER changes
+(tests/golden), so the bound is 2.6x the measured value / 2.7x the reference's own order-noise, not a 7x slack."""
 import types
 
 import pytest
@@ -13,6 +14,7 @@ from tests.util import max_abs, rel_l2
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
 LAT = (16, 24)
+TRAJ_TOL = 1.5e-2
 
 
 def _setup(mode="t2v", steps=2, with_vae=False):
@@ -60,7 +62,7 @@ def test_t2v_first_chunk_latents_and_handoff():
     e, eh = rel_l2(lat, o_out), rel_l2(got["h"], o_hand)
     print(f"t2v chunk 1: rel_l2 latents = {e:.3e}, hand-off = {eh:.3e}")
     assert got["h"].shape == (1, 8, 16, *LAT)
-    assert e < 4e-2 and eh < 4e-2
+    assert e < TRAJ_TOL and eh < TRAJ_TOL
     # hipGraph replay (default) and eager launches give bit-identical chunks
     pipe.use_graphs = False
     _, lat_eager = pipe.inference(noise.cuda(), ["a cat"], return_latents=True, decode=False)
@@ -72,7 +74,7 @@ def test_t2v_first_chunk_latents_and_handoff():
     o2, _, _ = _oracle(sd, cfg, ctx, noise, renoise, init, "t2v", 2)
     e2 = rel_l2(lat2, o2)
     print(f"t2v chunk 2 (initial_latent): rel_l2 = {e2:.3e}")
-    assert torch.equal(lat2[:, :2].cpu(), init) and e2 < 4e-2
+    assert torch.equal(lat2[:, :2].cpu(), init) and e2 < TRAJ_TOL
 
 
 def test_i2v_chunk_with_image_latent():
@@ -86,7 +88,7 @@ def test_i2v_chunk_with_image_latent():
     o_out, o_hand, _ = _oracle(sd, cfg, ctx, noise, None, img, "i2v", 2)
     e = rel_l2(lat, o_out)
     print(f"i2v: rel_l2 latents = {e:.3e}, hand-off = {rel_l2(got['h'], o_hand):.3e}")
-    assert got["h"].shape == (1, 3, 16, *LAT) and e < 4e-2
+    assert got["h"].shape == (1, 3, 16, *LAT) and e < TRAJ_TOL
 
 
 def test_decode_and_handoff_transform():

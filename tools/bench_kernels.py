@@ -53,17 +53,20 @@ def bench_attn(iters):
 def bench_gemm(iters):
     for name, M, N, K, epi in (("qkv", 25200, 15360, 5120, 0), ("o", 25200, 5120, 5120, 3), ("ffn0", 25200, 13824, 5120, 1),
                                ("ffn2", 25200, 5120, 13824, 3), ("qkv_s0", 7200, 15360, 5120, 0), ("sq8k", 8192, 8192, 8192, 0)):
-        A = torch.randn(M, K, device=dev).to(BF)
-        W = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(BF)
+        # BENCH_PAD_K / BENCH_PAD_N: extra elements in the leading dimension of the K-contiguous operands / of C and the residual
+        # (dev: does the power-of-two-ish row stride camp on a few HBM channels?)
+        pk, pn = int(os.environ.get("BENCH_PAD_K", "0")), int(os.environ.get("BENCH_PAD_N", "0"))
+        A = torch.randn(M, K + pk, device=dev).to(BF)
+        W = (torch.randn(N, K + pk, device=dev) / math.sqrt(K)).to(BF)
         b = torch.randn(N, device=dev).to(BF)
-        Cc = torch.empty(M, N, device=dev, dtype=BF)
-        res = torch.randn(M, N, device=dev).to(BF)
+        Cc = torch.empty(M, N + pn, device=dev, dtype=BF)
+        res = torch.randn(M, N + pn, device=dev).to(BF)
         gate = torch.randn(8, N, device=dev).to(BF)
-        fn = lambda: _lib.check(lib.mmpl_gemm(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(Cc), N, M, N, K, epi, _lib.ptr(res),
-                                              N, _lib.ptr(gate), N, 3600, _lib.stream_ptr()))
+        fn = lambda: _lib.check(lib.mmpl_gemm(_lib.ptr(A), K + pk, _lib.ptr(W), K + pk, _lib.ptr(b), _lib.ptr(Cc), N + pn, M, N, K, epi, _lib.ptr(res),
+                                              N + pn, _lib.ptr(gate), N, 3600, _lib.stream_ptr()))
         ctr = torch.zeros(8, dtype=torch.int32, device=dev)
-        fn_t = lambda: _lib.check(lib.mmpl_gemm_tickets(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(Cc), N, M, N, K, epi, _lib.ptr(res),
-                                                        N, _lib.ptr(gate), N, 3600, _lib.ptr(ctr), _lib.stream_ptr()))
+        fn_t = lambda: _lib.check(lib.mmpl_gemm_tickets(_lib.ptr(A), K + pk, _lib.ptr(W), K + pk, _lib.ptr(b), _lib.ptr(Cc), N + pn, M, N, K, epi, _lib.ptr(res),
+                                                        N + pn, _lib.ptr(gate), N, 3600, _lib.ptr(ctr), _lib.stream_ptr()))
         ms, ms_t = timeit(fn, iters), timeit(fn_t, iters)
         ms2, ms_t2 = timeit(fn, iters), timeit(fn_t, iters)
         ms, ms_t = min(ms, ms2), min(ms_t, ms_t2)
@@ -101,7 +104,8 @@ def gemm_phases(epi=3):
     t = Cc.view(-1).view(torch.float32)[: nblk * 16].view(-1, 4).double()
     t = t[t[:, 3] == K // 32]
     print(f"gemmphases epi={epi}: waves {len(t)}  prologue {t[:, 0].mean().item():.0f}  loop {t[:, 1].mean().item():.0f} "
-          f"({t[:, 1].mean().item() / (K // 32) / 32:.2f} per MFMA)  epilogue {t[:, 2].mean().item():.0f} (max {t[:, 2].max().item():.0f}) cycles", flush=True)
+          f"({t[:, 1].mean().item() / (K // 32) / 32:.2f} per MFMA; p5 {t[:, 1].quantile(0.05).item():.0f} p50 {t[:, 1].quantile(0.5).item():.0f} "
+          f"p95 {t[:, 1].quantile(0.95).item():.0f})  epilogue {t[:, 2].mean().item():.0f} (max {t[:, 2].max().item():.0f}) cycles", flush=True)
 
 
 def gemm_cycles():
