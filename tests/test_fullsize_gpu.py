@@ -121,7 +121,7 @@ def test_full_size_forward_heavy_tailed_14B_anchor_stage():
     overflow / redo path, bf16 q rounding) and 6 massive-activation channels in the residual stream (patch-embedding bias +-60 on
     6 columns: LayerNorm statistics, GEMM accumulation and the bf16 residual adds all see a 100x dynamic range).  Checker as
     above.  The oracle's own two executors differ more here too (sharp softmax amplifies a 1-ulp score change), hence the
-    separately stated bound of 3e-2."""
+    separately stated bound of 1.2e-2 (measured 6.2e-3 / 5.9e-3: the massive channels dominate both norms)."""
     def mutate(sd, cfg):
         for l in range(cfg["num_layers"]):
             for k in ("self_attn.norm_q.weight", "self_attn.norm_k.weight"):
@@ -131,7 +131,7 @@ def test_full_size_forward_heavy_tailed_14B_anchor_stage():
         sd["patch_embedding.bias"] = b.to(torch.bfloat16)
     errs = _stages("14B", (90, 160), mutate=mutate, n_stages=2, seed=33)
     print("14B (90, 160) heavy-tailed (QK gains x8, 6 massive channels): rel_l2(HIP, oracle on device) s0, s1 = " + ", ".join(f"{e:.3e}" for e in errs))
-    assert len(errs) == 2 and max(errs) < 3e-2
+    assert len(errs) == 2 and max(errs) < 1.2e-2
 
 
 def test_full_size_forward_i2v_stage_patterns():
