@@ -677,10 +677,11 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
   const int tiles = ((g.M + BM3 - 1) / BM3) * ((g.N + BN3 - 1) / BN3);
   GemmArgs g2 = g;
   static const int env_group = getenv("MMPL_GEMM_GROUP") ? atoi(getenv("MMPL_GEMM_GROUP")) : 0;
-  // M-tile group of the block order (how many row panels the tiles in flight on an XCD span).  Sweep with the staged epilogue
-  // and tile tickets on the 14B / 720p block shapes (TFLOP/s at group 2 / 3 / 4): qkv N=15360 1348 / 1323 / 1315, o N=5120
-  // 1256 / 1301 / 1261, ffn0 N=13824 1305 / 1300 / 1279, ffn2 K=13824 1267 / 1277 / 1278; M=7200 and 8192^3 prefer 4.
-  g2.group = env_group > 0 ? env_group : (g.M >= 16384 ? (g.N >= 8192 ? 2 : 3) : 4);
+  // M-tile group of the block order (how many row panels the tiles in flight on an XCD span).  Sweep with the sweep-synchronous
+  // order, nt stores and tile tickets on the 14B / 720p block shapes (TFLOP/s at group 2 / 3 / 4 / 8, profiles/r03d_*): qkv
+  // N=15360 1418 / 1431 / 1425 / 1397, ffn0 N=13824 1351 / 1360 / 1379 / 1338, o N=5120 1294 / 1336 / 1307 / 1317, ffn2 K=13824
+  // 1320 / 1312 / 1307 / 1313; M=7200 and 8192^3 prefer 4.
+  g2.group = env_group > 0 ? env_group : (g.M >= 16384 ? (g.N >= 8192 ? 4 : (g.K >= 8192 ? 2 : 3)) : 4);
   // the 16-byte epilogue needs 8-element alignment of everything it touches; otherwise the direct 8-byte one
   static const bool env_direct = getenv("MMPL_GEMM_DIRECT_EPILOGUE") != nullptr;
   // (strides AND base pointers: mmpl_gemm is public ABI and callers hand in views such as a column-offset C)
