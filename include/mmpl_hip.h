@@ -85,8 +85,9 @@ int mmpl_attn_fwd_ws(const void* q, int ldq, void* o, int ldo, const void* const
                      int ldk, int ldv, int n_pages, int page_rows, int Lq, int num_heads, float softmax_scale,
                      void* workspace, size_t workspace_bytes, mmpl_stream_t stream);
 
-/* Same, with the kernel chosen by the caller (tests and A/B runs): variant 0 = what mmpl_attn_fwd_ws picks (the ping-pong
- * kernel), 1 = lock-step 8 x 32 rows (the kernel the text cross-attention uses), 2 = ping-pong 8 x 32 rows, 3 = 4 waves x 64
+/* Same, with the kernel chosen by the caller (tests and A/B runs): variant 0 = what mmpl_attn_fwd_ws picks (the lock-step
+ * kernel for a raw q), 1 = lock-step 8 x 32 rows (the kernel the text cross-attention uses), 2 = removed (round 1's ping-pong
+ * kernel: error), 3 = 4 waves x 64
  * rows (the DiT forward's self-attention kernel) on a raw q, 4 = the same on a q its producer already multiplied by
  * softmax_scale * log2(e) before rounding it to bf16 (what mmpl_dit_forward does: one rounding of q instead of two).
  * cross != 0 tags the launch as a text cross-attention launch (kernel symbol of variant 1 only).  Unknown variant: error. */

@@ -11,6 +11,7 @@
 
 #include "../../include/mmpl_hip.h"
 #include "kernels.h"
+#include "mmpl_config.h"
 
 static thread_local std::string g_err;
 static int fail(const char* where, const char* what) {
@@ -328,7 +329,7 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
   const float scale = 1.0f / sqrtf(128.0f);
   const int self_variant = mmpl_attention_self_variant();
   const bool prescale_q = self_variant == ATTN_W64;         // fold scale * log2(e) into q before it is rounded (kernels.h)
-  static const bool cross_w64_env = getenv("MMPL_CROSS_W64") != nullptr;
+  const bool cross_w64_env = mmpl_config().cross_w64;
   const bool cross_w64 = cross_w64_env && prescale_q;       // text / image cross-attention on the 64-rows-per-wave kernel too
   const size_t layer_stride = (size_t)n_slots * S * d;
   for (int l = 0; l < c.num_layers; ++l) {
@@ -449,7 +450,8 @@ int mmpl_attn_fwd_variant(const void* q, int ldq, void* o, int ldo, const void* 
                           int ldk, int ldv, int n_pages, int page_rows, int Lq, int num_heads, float softmax_scale,
                           void* workspace, size_t workspace_bytes, int variant, int cross, mmpl_stream_t stream) {
   if (n_pages < 1 || n_pages > MMPL_MAX_PAGES) return fail("mmpl_attn_fwd", "n_pages out of range");
-  if (variant < ATTN_AUTO || variant > ATTN_W64 + 1) return fail("mmpl_attn_fwd", "unknown kernel variant");
+  if (variant != ATTN_AUTO && variant != ATTN_LOCKSTEP && variant != ATTN_W64 && variant != ATTN_W64 + 1)
+    return fail("mmpl_attn_fwd", "unknown kernel variant");
   AttnArgs a = {};
   a.variant = variant > ATTN_W64 ? ATTN_W64 : variant;
   a.q_prescaled = variant == ATTN_W64 + 1;

@@ -4,10 +4,12 @@
 // attention.py:139-185): K/V are read IN PLACE from the per-layer KV cache through a table of page (frame
 // slot) base pointers, so no gather copy exists.
 //
-// Three kernels share the math, the page table and the fragment layouts; mmpl_launch_attention (end of this file) picks:
+// Two kernels share the math, the page table and the fragment layouts; mmpl_launch_attention (end of this file) picks:
 //   attn_w64_kernel (attn_w64.hip)  the DiT forward's self-attention: one wave per SIMD, 64 query rows per wave (default)
-//   attn_pp_kernel  (below)         round 1's default; today a raw-q caller of the attention() seam, and MMPL_ATTN_PP=1
-//   attn_fwd_kernel (below)         the lock-step original: text / image cross-attention, the CLIP tower, MMPL_ATTN_V1=1
+//   attn_fwd_kernel (below)         the lock-step original: text / image cross-attention, the CLIP tower, raw-q callers of the
+//                                   attention() seam, MMPL_ATTN_V1=1
+// (round 1's ping-pong kernel, attn_pp_kernel -- 8 waves, two groups half an iteration apart, 1010-1060 TFLOP/s -- was removed in
+// round 3: attn_w64_kernel superseded it on the hot path and nothing else needed its speed; DESIGN.md section 3.1 keeps its record)
 //
 // attn_fwd_kernel:
 // 512 threads = 8 waves, each wave owns 32 query rows (Q fragments live in registers);
@@ -23,6 +25,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "mmpl_config.h"
 
 namespace {
 
@@ -249,331 +252,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs a) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// v2 "ping-pong" (round 1's default for self-attention): same math and fragment layouts as attn_fwd_kernel, but the 8 waves of
-// the (single) resident block are split into two groups that run half an iteration apart.  Per KV tile j a wave runs
-//   M_j = { O += V(j-1).P(j-1) ; S(j) = K(j).Q }   32 MFMAs, LDS fragments requested 6 ahead, 4 LDS-DMA ops
-//   V_j = { online softmax of S(j) -> P(j) }        ~200 VALU (32 exp2)
-// and while the waves of one group are in M the co-resident waves of the other group (same SIMDs: waves w and w+4)
-// are in V, so every SIMD has one wave feeding the matrix pipe and one on the VALU instead of all eight contending
-// for the same pipe in lock-step.  One raw s_barrier per segment boundary keeps the groups in opposite phase.
-// K/V tiles go global -> LDS by DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write) into rings of 4 (K) and
-// 5 (V) tiles, issued three tiles ahead and ordered with counted s_waitcnt vmcnt; the LDS image is lane-linear, so
-// the bank-conflict swizzle is applied to the per-lane SOURCE chunk (K: chunk ^= row & 15; V: chunk ^= (row & 3) << 2)
-// and again on the fragment reads (SQ_LDS_BANK_CONFLICT = 0).
-//
-// Measured on MI355X (profiles/r01f_*, same box, 14B/720p shapes): +6 % (s1) ... +14 % (s3) over attn_fwd_kernel.
-// Cycle counters inside the kernel (s_memtime per segment) say where the rest goes: M = 1650-2000 cycles for 1024
-// cycles of MFMA (each LDS-DMA op stalls its in-order wave ~110 cycles at issue: the LDS-DMA path delivers ~17 B/clk/CU
-// and this kernel asks for 70 % of that; with the DMA ops removed M = 1200, with the fragment reads removed too 1034),
-// V = 1250-1400.  Tried and rejected on this structure: {QK+softmax | PV} split (-1 %), exponentials interleaved
-// under the PV MFMAs (-10 %), DMA ops issued from the vector segment (-8 %) or staggered by wave (-9 %), register
-// staging instead of DMA (-4 %, 250 VGPRs), static / per-group priorities (-2..-5 %).
-constexpr int PP_RK = 4, PP_RV = 5, PP_TILE = KVB * 256;
-constexpr int PP_SMEM = (PP_RK + PP_RV) * PP_TILE;      // 147456
-
-// LDS-DMA issued from inline asm: hipcc cannot disambiguate LDS-DMA writes from later LDS reads and would put an
-// s_waitcnt vmcnt(0) in front of the next ds_read (draining the prefetch it was meant to overlap); ordering is done
-// by the explicit counted waits below instead.  (M0 = wave-uniform LDS destination; 1 wait state after the M0 write.
-// M0 is a reserved register that hipcc only ever sets immediately before an instruction of its own that needs it, and
-// this kernel has no such instruction, so it is not listed as a clobber.)
-MMPL_DEV void glds16(const void* base, uint32_t voff, char* lds) {   // base: wave-uniform; voff: per-lane byte offset
-  const uint32_t dst = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)lds);
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(dst) : "memory");
-}
-
-// SPLIT (the tail round, see mmpl_launch_attention): the block handles KV tiles [part*T/sp, (part+1)*T/sp) of query block
-// `local_base + idx / sp` and writes an un-normalised fp32 partial (O, m, l) for attn_merge_kernel.
-template <bool SPLIT>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_pp_kernel(AttnArgs a, int local_base, int sp) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2;            // waves w and w+4 share a SIMD (dispatch order cycles over the 4 SIMDs)
-  const int hi = lane >> 5, l31 = lane & 31;
-
-  const int n_qb = (a.Lq + QB - 1) / QB;
-  int head, qb, part = 0, tail_idx = 0;
-  if (SPLIT) {
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    part = idx % sp;
-    tail_idx = idx / sp;
-    const int local = local_base + tail_idx;
-    head = xcd + 8 * (local / n_qb);
-    qb = local % n_qb;
-    tail_idx = xcd * (gridDim.x / (8 * sp)) + tail_idx;
-  } else if ((a.H & 7) == 0) {
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    head = xcd + 8 * (local / n_qb);
-    qb = local % n_qb;
-  } else {
-    // any other head count (Wan 1.3B: 12): the hardware deals blocks round-robin to the 8 XCDs, so XCD x is given the x-th
-    // contiguous chunk of the head-major (head, query block) list -- the blocks sharing one L2 work on at most a few heads;
-    // the grid is padded to 8 chunks (launcher), the padding blocks leave at once
-    const int total = n_qb * a.H, per = (total + 7) >> 3;
-    const int item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (item >= total) return;
-    head = item / n_qb;
-    qb = item % n_qb;
-  }
-
-  const int qrow = min(qb * QB + wave * QW + l31, a.Lq - 1);
-  bf16x8 qf[8];
-  {
-    const bf16_t* qp = a.q + (size_t)qrow * a.ldq + head * 128 + 8 * hi;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) qf[c] = *reinterpret_cast<const bf16x8*>(qp + 16 * c);
-    // complete the Q loads HERE in the compiler's view too: otherwise it waits for them lazily inside the main loop
-    // with vmcnt(7..0), which also drains the LDS-DMA prefetch (invisible to its counters) every iteration
-#pragma unroll
-    for (int c = 0; c < 8; ++c) asm volatile("" ::"v"(qf[c]));
-  }
-
-  const int tiles_pp = (a.page_rows + KVB - 1) / KVB;
-  const int T_all = a.n_pages * tiles_pp;
-  const int t_first = SPLIT ? (int)((long long)part * T_all / sp) : 0;
-  const int T = SPLIT ? (int)((long long)(part + 1) * T_all / sp) - t_first : T_all;     // tiles of THIS block
-  char* const kring = smem;
-  char* const vring = smem + PP_RK * PP_TILE;
-
-  // ---- DMA roles: wave w moves pieces w and w + 8 (4 rows x 256 B each) of the K tile and of the V tile.  A DMA op is
-  // global_load_lds_dwordx4 voff, s[base]: the per-lane byte offsets (row * ld + swizzled chunk) are computed once,
-  // the wave-uniform base (page, first row of the tile, head) per tile; only a page's ragged last tile re-clamps rows.
-  const int drow = lane >> 4, dchunk = lane & 15;
-  uint32_t dko[2], dvo[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int row = 4 * (wave + 8 * h) + drow;
-    dko[h] = (uint32_t)(row * a.ldk + ((dchunk ^ (row & 15)) << 3)) * 2u;
-    dvo[h] = (uint32_t)(row * a.ldv + ((dchunk ^ ((row & 3) << 2)) << 3)) * 2u;
-  }
-  int ipg = t_first / tiles_pp, irow0 = (t_first % tiles_pp) * KVB, it = 0;          // next tile to issue
-  // wave-uniform source pointers of that tile (first row, this head).  They are advanced / re-read from the page table
-  // in issue_advance() and PINNED there: a scalar load first used inside the matrix segment would put an
-  // s_waitcnt lgkmcnt(0) in front of the DMA op, draining the wave's whole LDS fragment prefetch window each time
-  const bf16_t* kcur = a.k_pages[ipg] + (size_t)irow0 * a.ldk + head * 128;
-  const bf16_t* vcur = a.v_pages[ipg] + (size_t)irow0 * a.ldv + head * 128;
-  asm volatile("" : "+s"(kcur), "+s"(vcur));
-  // piece k of the tile being issued: 0 = K rows 0..31 share, 1 = V, 2 = K rows 32..63 share, 3 = V
-  auto issue_piece = [&](int k) {
-    const int h = k >> 1;
-    const bool isv = k & 1;
-    const int ld = isv ? a.ldv : a.ldk;
-    char* dst = (isv ? vring + (it % PP_RV) * PP_TILE : kring + (it % PP_RK) * PP_TILE) + (wave + 8 * h) * 1024;
-    uint32_t off = isv ? dvo[h] : dko[h];
-    if (irow0 + KVB > a.page_rows) {             // ragged tail: clamp to the page's last row (masked in the softmax)
-      const int row = 4 * (wave + 8 * h) + drow, r = min(row, a.page_rows - 1 - irow0);
-      off = (uint32_t)(r * ld + ((dchunk ^ (isv ? ((row & 3) << 2) : (row & 15))) << 3)) * 2u;
-    }
-    glds16(isv ? vcur : kcur, off, dst);
-  };
-  auto issue_advance = [&]() {
-    ++it;
-    irow0 += KVB;
-    kcur += (size_t)KVB * a.ldk;
-    vcur += (size_t)KVB * a.ldv;
-    if (irow0 >= a.page_rows) {
-      irow0 = 0;
-      ++ipg;
-      if (ipg < a.n_pages) {
-        kcur = a.k_pages[ipg] + head * 128;
-        vcur = a.v_pages[ipg] + head * 128;
-      }
-    }
-    asm volatile("" : "+s"(kcur), "+s"(vcur));
-  };
-  auto issue_tile = [&]() {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) issue_piece(k);
-    issue_advance();
-  };
-
-  f32x16 o[4];
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-  const float c = a.scale * 1.4426950408889634f;
-
-  // ---- per-lane fragment read offsets (swizzled)
-  int koff[8];
-#pragma unroll
-  for (int cs = 0; cs < 8; ++cs) koff[cs] = l31 * 256 + 32 * (cs ^ ((l31 & 15) >> 1)) + 16 * (hi ^ (l31 & 1));
-  const int i16 = lane & 15, g16 = (lane >> 4) & 1;
-  int voff[4];
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb) voff[nb] = (4 * hi + (i16 >> 2)) * 256 + 64 * (nb ^ (i16 >> 2)) + 32 * g16 + 8 * (i16 & 3);
-
-  // ---- prologue: tiles 0..2 in flight, tile 0 landed
-  issue_tile();
-  if (T > 1) issue_tile();
-  if (T > 2) issue_tile();
-  if (T > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (T > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (grp == 1) __builtin_amdgcn_s_barrier();      // group B runs half an iteration late
-
-  f32x16 s0, s1;
-  bf16x8 pb[2][2];
-  int crow0 = (t_first % tiles_pp) * KVB;           // first kv row (within its page) of compute tile j
-  constexpr int PD = 6;                             // LDS fragments requested ahead of the MFMA that consumes them
-
-  // ---- M_j: 16 PV MFMAs of tile j-1, then 16 QK^T MFMAs of tile j (two accumulator chains, alternating).  The LDS
-  // fragment of step i+PD is requested right after the MFMA of step i (a rotating register window pinned with
-  // sched_barrier: left alone hipcc reads one fragment ahead and every MFMA eats an LDS round trip).  The four DMA ops
-  // of tile j+3 go out one per quarter of the segment so the address path drains in between.
-  auto m_segment = [&](auto do_pv, auto do_qk, int j) {
-    constexpr bool PV = decltype(do_pv)::value, QK = decltype(do_qk)::value;
-    constexpr int I0 = PV ? 0 : 16, I1 = QK ? 32 : 16;
-    constexpr int SH = PV && QK ? 3 : 2, MASK = (1 << SH) - 1;
-    const bool do_issue = j + 3 < T;
-    const char* kb = kring + (j % PP_RK) * PP_TILE;
-    const char* vb = vring + ((j + PP_RV - 1) % PP_RV) * PP_TILE;      // tile j-1
-    auto frag = [&](int i) -> bf16x8 {
-      if (i < 16) {                               // V^T fragment: i = 8*h + 4*cc + nb
-        const char* vp = vb + voff[i & 3] + (32 * (i >> 3) + 16 * ((i >> 2) & 1)) * 256;
-        return tr_pair(vp, vp + 8 * 256);
-      }
-      const int q = i - 16;                       // K fragment: kv half = q & 1, hd chunk = q >> 1
-      return *reinterpret_cast<const bf16x8*>(kb + koff[q >> 1] + (q & 1) * (32 * 256));
-    };
-    f32x16 zero;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-    bf16x8 w[PD];
-#pragma unroll
-    for (int i = 0; i < PD; ++i) w[i] = frag(I0 + i);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = I0; i < I1; ++i) {
-      const bf16x8 f = w[(i - I0) % PD];
-      if (i < 16) o[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, pb[i >> 3][(i >> 2) & 1], o[i & 3], 0, 0, 0);
-      else if ((i & 1) == 0) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, qf[(i - 16) >> 1], i == 16 ? zero : s0, 0, 0, 0);
-      else s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, qf[(i - 16) >> 1], i == 17 ? zero : s1, 0, 0, 0);
-      if (i + PD < I1) w[(i - I0) % PD] = frag(i + PD);
-      if (((i - I0) & MASK) == 1 && do_issue) issue_piece((i - I0) >> SH);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (do_issue) issue_advance();
-    __builtin_amdgcn_s_setprio(0);
-  };
-  // ---- V_j: online softmax of S(j) -> P(j) (bf16 B-fragments in pb)
-  auto v_segment = [&]() {
-    // S(j) is consumed HERE, P(j) is complete at the end of this segment: without the two pins hipcc moves the vector
-    // work across the (memory-only) barriers into the neighbouring matrix segments, where it serialises with the MFMAs
-    asm volatile("" : "+v"(s0), "+v"(s1));
-    const int valid = a.page_rows - crow0;
-    if (valid < KVB) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kv = 8 * (r >> 2) + 4 * hi + (r & 3);
-        if (kv >= valid) s0[r] = -INFINITY;
-        if (kv + 32 >= valid) s1[r] = -INFINITY;
-      }
-    }
-    crow0 += KVB;
-    if (crow0 >= a.page_rows) crow0 = 0;
-    float mx = s0[0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[r]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    // exact lazy rescale: only when some row's running max actually grew (rare after the first tiles)
-    if (__any(m_new > m_run)) {
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-      l_run *= alpha;
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[nb][r] *= alpha;
-      m_run = m_new;
-    }
-    const float mc = m_run * c;
-    float ls0 = 0.f, ls1 = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s0[r] = __builtin_amdgcn_exp2f(s0[r] * c - mc); ls0 += s0[r]; }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s1[r] = __builtin_amdgcn_exp2f(s1[r] * c - mc); ls1 += s1[r]; }
-    l_run += ls0 + ls1;
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {
-      union { uint32_t u[4]; bf16x8 v; } x0, x1;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        x0.u[q] = pack2bf(s0[8 * cc + 2 * q], s0[8 * cc + 2 * q + 1]);
-        x1.u[q] = pack2bf(s1[8 * cc + 2 * q], s1[8 * cc + 2 * q + 1]);
-      }
-      pb[0][cc] = x0.v;
-      pb[1][cc] = x1.v;
-    }
-    asm volatile("" : "+v"(pb[0][0]), "+v"(pb[0][1]), "+v"(pb[1][0]), "+v"(pb[1][1]), "+v"(l_run));
-  };
-  // Before the barrier that precedes the first reader of tile j+1 every wave's four DMA ops of it must have landed;
-  // tile j+2 and (if already issued: group A waits after its M_j, group B one segment earlier) tile j+3 stay in flight.
-  auto dma_wait = [&](int j, bool issued_j3) {
-    const int younger = (j + 2 < T ? 4 : 0) + (issued_j3 && j + 3 < T ? 4 : 0);
-    if (younger == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (younger == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
-  using std::true_type;
-  using std::false_type;
-
-  m_segment(false_type{}, true_type{}, 0);
-  if (grp == 1) dma_wait(0, true);
-  __builtin_amdgcn_s_barrier();
-  v_segment();
-  if (grp == 0) dma_wait(0, true);
-  __builtin_amdgcn_s_barrier();
-  for (int j = 1; j < T; ++j) {
-    m_segment(true_type{}, true_type{}, j);
-    if (grp == 1) dma_wait(j, true);
-    __builtin_amdgcn_s_barrier();
-    v_segment();
-    if (grp == 0) dma_wait(j, true);
-    __builtin_amdgcn_s_barrier();
-  }
-  m_segment(true_type{}, false_type{}, T);
-  if (grp == 0) __builtin_amdgcn_s_barrier();
-
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  if (SPLIT) {
-    // partial of this KV range: O (fp32, relative to m_run), then m, l per row -- [tail block][part][256 rows][128 + 2]
-    float* pbase = a.split_ws + ((size_t)tail_idx * sp + part) * (QB * 130);
-    const int rr = wave * QW + l31;
-    float* op = pbase + (size_t)rr * 128 + 4 * hi;
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<f32x4*>(op + 32 * nb + 8 * g) = f32x4{o[nb][4 * g], o[nb][4 * g + 1], o[nb][4 * g + 2], o[nb][4 * g + 3]};
-    if (hi == 0) {
-      pbase[QB * 128 + rr] = m_run;
-      pbase[QB * 129 + rr] = l_tot;
-    }
-    return;
-  }
-  const float inv = 1.0f / l_tot;
-  const int q_out = qb * QB + wave * QW + l31;
-  if (q_out < a.Lq) {
-    bf16_t* op = a.o + (size_t)q_out * a.ldo + head * 128 + 4 * hi;
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        uint2 w;
-        w.x = pack2bf(o[nb][4 * g] * inv, o[nb][4 * g + 1] * inv);
-        w.y = pack2bf(o[nb][4 * g + 2] * inv, o[nb][4 * g + 3] * inv);
-        *reinterpret_cast<uint2*>(op + 32 * nb + 8 * g) = w;
-      }
-  }
-}
-
 // Combine the `sp` KV-range partials of each tail query block: O = sum_p w_p O_p / sum_p w_p l_p, w_p = 2^((m_p - m) c).
 __global__ __launch_bounds__(256) void attn_merge_kernel(AttnArgs a, int local_base, int sp, int tb) {
   __shared__ float wgt[QB][4];
@@ -616,15 +294,8 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnArgs a, int local_b
 
 size_t mmpl_attention_split_ws_bytes() { return (size_t)256 * QB * 130 * sizeof(float); }   // <= one block per CU in the tail round
 
-namespace {
-bool env_flag(const char* name) { const char* v = getenv(name); return v && atoi(v); }
-}  // namespace
-
-// MMPL_ATTN_V1=1 / MMPL_ATTN_PP=1: A/B runs of a whole forward on the lock-step / ping-pong kernel (read once per process)
-int mmpl_attention_self_variant() {
-  static const int v = env_flag("MMPL_ATTN_V1") ? ATTN_LOCKSTEP : env_flag("MMPL_ATTN_PP") ? ATTN_PINGPONG : ATTN_W64;
-  return v;
-}
+// MMPL_ATTN_V1=1: A/B runs of a whole forward on the lock-step kernel (mmpl_config.h)
+int mmpl_attention_self_variant() { return mmpl_config().attn_v1 ? ATTN_LOCKSTEP : ATTN_W64; }
 
 namespace {
 // Pages that lie back to back in memory (the KV-cache slots of one layer are one allocation; so are a stage's scratch pages) are
@@ -672,21 +343,21 @@ AttnArgs merge_contiguous_pages(const AttnArgs& a) {
 hipError_t mmpl_launch_attention(const AttnArgs& a_in, hipStream_t s) {
   if (a_in.Lq <= 0) return hipSuccess;
   if (a_in.n_pages <= 0 || a_in.n_pages > MMPL_MAX_PAGES) return hipErrorInvalidValue;
-  static const bool no_merge = env_flag("MMPL_ATTN_NO_MERGE");
+  const bool no_merge = mmpl_config().attn_no_merge;
   const bool w64_bound = a_in.variant == ATTN_W64 || (a_in.variant == ATTN_AUTO && !a_in.cross && a_in.q_prescaled && mmpl_attention_self_variant() == ATTN_W64);
   const AttnArgs a = (!no_merge && w64_bound && a_in.n_pages > 1) ? merge_contiguous_pages(a_in) : a_in;
   if (a.n_pages <= 0 || a.n_pages > MMPL_MAX_PAGES || a.page_rows <= 0 || (a.ldq % 8) || (a.ldk % 8) || (a.ldv % 8) ||
-      (a.ldo % 4) || a.variant < ATTN_AUTO || a.variant > ATTN_W64)
+      (a.ldo % 4) || (a.variant != ATTN_AUTO && a.variant != ATTN_LOCKSTEP && a.variant != ATTN_W64))
     return hipErrorInvalidValue;
   // Kernel choice.  The DiT forward's self-attention (q prescaled by its producer) -> the 64-rows-per-wave kernel
   // (attn_w64.hip); the 8-tile text cross-attention -> the lock-step kernel (its prologue is the shortest); a raw-q launch
-  // (the attention() seam) -> the ping-pong kernel (see mmpl_attention_self_variant).  AttnArgs.variant (C ABI:
-  // mmpl_attn_fwd_variant) selects one explicitly.
-  static const bool no_split = env_flag("MMPL_ATTN_NOSPLIT");
+  // (the attention() seam) -> the lock-step kernel too (exact online softmax on the caller's q; attn_w64 would round q a second
+  // time, kernels.h).  AttnArgs.variant (C ABI: mmpl_attn_fwd_variant) selects one explicitly.
+  const bool no_split = mmpl_config().attn_nosplit;
   int variant = a.variant;
   if (variant == ATTN_AUTO) {
     variant = a.cross ? ATTN_LOCKSTEP : mmpl_attention_self_variant();
-    if (variant == ATTN_W64 && !a.q_prescaled) variant = ATTN_PINGPONG;
+    if (variant == ATTN_W64 && !a.q_prescaled) variant = ATTN_LOCKSTEP;
   }
   if (a.q_prescaled && variant != ATTN_W64) return hipErrorInvalidValue;
   const int n_qb = (a.Lq + QB - 1) / QB;
@@ -697,20 +368,9 @@ hipError_t mmpl_launch_attention(const AttnArgs& a_in, hipStream_t s) {
     else hipLaunchKernelGGL(attn_fwd_kernel<0>, dim3(n_qb * a.H), dim3(512), SMEM, s, a);
     return hipGetLastError();
   }
-  const bool w64 = variant == ATTN_W64;
-  if (hipError_t e = w64 ? mmpl_dyn_smem_once(mmpl_attention_w64_symbol(0), mmpl_attention_w64_smem())
-                         : mmpl_dyn_smem_once(reinterpret_cast<const void*>(attn_pp_kernel<false>), PP_SMEM);
-      e != hipSuccess)
-    return e;
-  if (hipError_t e = w64 ? mmpl_dyn_smem_once(mmpl_attention_w64_symbol(1), mmpl_attention_w64_smem())
-                         : mmpl_dyn_smem_once(reinterpret_cast<const void*>(attn_pp_kernel<true>), PP_SMEM);
-      e != hipSuccess)
-    return e;
-  auto run = [&](int blocks, int local_base, int sp, bool split) {
-    if (w64) mmpl_launch_attention_w64(a, blocks, local_base, sp, split, s);
-    else if (split) hipLaunchKernelGGL(attn_pp_kernel<true>, dim3(blocks), dim3(512), PP_SMEM, s, a, local_base, sp);
-    else hipLaunchKernelGGL(attn_pp_kernel<false>, dim3(blocks), dim3(512), PP_SMEM, s, a, local_base, sp);
-  };
+  if (hipError_t e = mmpl_dyn_smem_once(mmpl_attention_w64_symbol(0), mmpl_attention_w64_smem()); e != hipSuccess) return e;
+  if (hipError_t e = mmpl_dyn_smem_once(mmpl_attention_w64_symbol(1), mmpl_attention_w64_smem()); e != hipSuccess) return e;
+  auto run = [&](int blocks, int local_base, int sp, bool split) { mmpl_launch_attention_w64(a, blocks, local_base, sp, split, s); };
   // Tail round: with one block per CU and b = n_qb*H/8 query blocks per XCD (32 CUs), the last b mod 32 blocks of every
   // XCD would run alone for a whole block time.  They are launched instead as `sp` blocks each over 1/sp of the KV tiles
   // (fp32 partials in split_ws) followed by a small merge kernel, so the tail round lasts ~1/sp block times.

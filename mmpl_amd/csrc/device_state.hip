@@ -34,3 +34,24 @@ int mmpl_cus_per_xcd() {
   }
   return g_per_xcd[dev];
 }
+
+
+// ---------------------------------------------------------------- run-time switches (mmpl_config.h)
+#include <stdlib.h>
+
+#include "mmpl_config.h"
+const MmplRuntimeConfig& mmpl_config() {
+  static const MmplRuntimeConfig cfg = [] {
+    auto flag = [](const char* n) { const char* v = getenv(n); return v != nullptr && atoi(v) != 0; };
+    auto num = [](const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; };
+    MmplRuntimeConfig c{};
+    c.attn_v1 = flag("MMPL_ATTN_V1"); c.attn_nosplit = flag("MMPL_ATTN_NOSPLIT"); c.attn_no_merge = flag("MMPL_ATTN_NO_MERGE");
+    c.cross_w64 = flag("MMPL_CROSS_W64");
+    c.gemm_v1 = flag("MMPL_GEMM_V1"); c.gemm_v2 = flag("MMPL_GEMM_V2"); c.gemm_direct_epilogue = flag("MMPL_GEMM_DIRECT_EPILOGUE");
+    c.gemm_static_tiles = flag("MMPL_GEMM_STATIC_TILES"); c.gemm_no_sync_sweeps = flag("MMPL_GEMM_NO_SYNC_SWEEPS");
+    c.gemm_group = num("MMPL_GEMM_GROUP", 0);
+    c.gemm_pf = num("MMPL_GEMM_PF", 2);
+    return c;
+  }();
+  return cfg;
+}

@@ -12,6 +12,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "mmpl_config.h"
 
 namespace {
 
@@ -661,7 +662,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       tp[0] = (float)(tk1 - tk0);
       tp[1] = (float)(tk2 - tk1);
       tp[2] = (float)(tk3 - tk2);
-      tp[3] = (float)(2 * nt);                                // in 32-wide k stages, like gemm_w64
+      tp[3] = (float)(2 * nt);                                // in 32-wide k stages
     }
   }
   if (g.pf_dist > 0 && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // prefetch DMAs target this block's LDS
@@ -676,14 +677,15 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
   if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v6_kernel<EPI>), smem); e != hipSuccess) return e;
   const int tiles = ((g.M + BM3 - 1) / BM3) * ((g.N + BN3 - 1) / BN3);
   GemmArgs g2 = g;
-  static const int env_group = getenv("MMPL_GEMM_GROUP") ? atoi(getenv("MMPL_GEMM_GROUP")) : 0;
+  const MmplRuntimeConfig& rc = mmpl_config();
+  const int env_group = rc.gemm_group;
   // M-tile group of the block order (how many row panels the tiles in flight on an XCD span).  Sweep with the sweep-synchronous
   // order, nt stores and tile tickets on the 14B / 720p block shapes (TFLOP/s at group 2 / 3 / 4 / 8, profiles/r03d_*): qkv
   // N=15360 1418 / 1431 / 1425 / 1397, ffn0 N=13824 1351 / 1360 / 1379 / 1338, o N=5120 1294 / 1336 / 1307 / 1317, ffn2 K=13824
   // 1320 / 1312 / 1307 / 1313; M=7200 and 8192^3 prefer 4.
   g2.group = env_group > 0 ? env_group : (g.M >= 16384 ? (g.N >= 8192 ? 4 : (g.K >= 8192 ? 2 : 3)) : 4);
   // the 16-byte epilogue needs 8-element alignment of everything it touches; otherwise the direct 8-byte one
-  static const bool env_direct = getenv("MMPL_GEMM_DIRECT_EPILOGUE") != nullptr;
+  const bool env_direct = rc.gemm_direct_epilogue;
   // (strides AND base pointers: mmpl_gemm is public ABI and callers hand in views such as a column-offset C)
   auto al = [](const void* p, uintptr_t a) { return p == nullptr || reinterpret_cast<uintptr_t>(p) % a == 0; };
   bool ptrs_ok = al(g.C, 16) && al(g.bias, 8);
@@ -697,12 +699,9 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
                        (g.epi != EPI_BIAS_VPAGES || (g.v_col0 % 8 == 0 && g.v_ld % 8 == 0));
   // L2 prefetch distance (k-tiles): 2 measured best on the 14B / 720p block shapes (+1 % qkv / o / ffn0, +6 % ffn2 whose A operand is
   // 700 MB; 1 = no gain, 4 and more lose again); MMPL_GEMM_PF=0 switches it off
-  static const int env_pf = getenv("MMPL_GEMM_PF") ? atoi(getenv("MMPL_GEMM_PF")) : 2;
-  g2.pf_dist = env_pf;
-  static const bool env_nosync = getenv("MMPL_GEMM_NO_SYNC_SWEEPS") != nullptr;
-  g2.sync_sweeps = !env_nosync;
-  static const bool env_static = getenv("MMPL_GEMM_STATIC_TILES") != nullptr;
-  if (env_static) g2.tile_counter = nullptr;
+  g2.pf_dist = rc.gemm_pf;
+  g2.sync_sweeps = !rc.gemm_no_sync_sweeps;
+  if (rc.gemm_static_tiles) g2.tile_counter = nullptr;
   const int n_cu = 8 * mmpl_cus_per_xcd();
   const int blocks = g2.tile_counter && tiles > n_cu ? n_cu : tiles;
   if (blocks == tiles) g2.tile_counter = nullptr;             // one round or less: nothing to balance
@@ -721,13 +720,10 @@ hipError_t launch_v2(const GemmArgs& g, hipStream_t s) {
 
 template <int EPI>
 hipError_t launch(const GemmArgs& g, hipStream_t s) {
-  // kernel-selection overrides for A/B runs, read once per process
-  static const bool env_v1 = getenv("MMPL_GEMM_V1") != nullptr, env_v2 = getenv("MMPL_GEMM_V2") != nullptr;
-  // gemm_w64.hip (one wave per SIMD, 4-deep ring, residual fetched by the k loop's tail) keeps the matrix pipe 85 % busy
-  // inside its k loop but is not faster end to end on this chip (in situ 1174 vs 1213 TFLOP/s: both run against the power
-  // limit, and its idle epilogue does not give the clock back -- DESIGN.md section 3.2), so it is opt-in: MMPL_GEMM_W64=1
-  static const bool env_w64 = getenv("MMPL_GEMM_W64") != nullptr;
-  if (env_w64 && !env_v1 && !env_v2 && mmpl_gemm_w64_accepts(g)) return mmpl_launch_gemm_w64(g, s);
+  // kernel-selection overrides for A/B runs (mmpl_config.h).  (gemm_w64.hip -- one wave per SIMD, 32x32x16 MFMAs, 85 % matrix-pipe
+  // issue rate inside its k loop yet 3-6 % slower end to end than v6 on this power-limited chip -- was removed in round 3;
+  // DESIGN.md section 3.2 keeps what it taught.)
+  const bool env_v1 = mmpl_config().gemm_v1, env_v2 = mmpl_config().gemm_v2;
   const bool big = g.batch <= 1 && g.M >= 1024 && g.N >= 256 && g.K >= 128 && !env_v1 && !env_v2;
   // v6 addresses its operands with 32-bit byte offsets from the base pointers; anything larger goes to v2 (64-bit pointers)
   if (big && (long long)g.M * g.lda < (1ll << 31) && (long long)g.N * g.ldw < (1ll << 31)) return launch_v6<EPI>(g, s);

@@ -37,8 +37,6 @@ struct GemmArgs {
   int sync_sweeps;               // v6: deal whole M-groups to the XCDs so that all of them sweep W's column panels together (set by the launcher)
 };
 hipError_t mmpl_launch_gemm(const GemmArgs& g, hipStream_t s);
-bool mmpl_gemm_w64_accepts(const GemmArgs& g);                      // gemm_w64.hip: the one-wave-per-SIMD kernel for the large linears
-hipError_t mmpl_launch_gemm_w64(const GemmArgs& g, hipStream_t s);
 
 // ---------------------------------------------------------------- attention (attention.hip)
 constexpr int MMPL_MAX_PAGES = 24;
@@ -56,11 +54,11 @@ struct AttnArgs {
   int variant;                     // ATTN_* kernel selector (0 = auto)
   int q_prescaled;                 // q was already multiplied by scale * log2(e) by its producer (ATTN_W64 only)
 };
-enum { ATTN_AUTO = 0, ATTN_LOCKSTEP = 1, ATTN_PINGPONG = 2, ATTN_W64 = 3 };
+enum { ATTN_AUTO = 0, ATTN_LOCKSTEP = 1, ATTN_W64 = 3 };      // (2 was the round-1 ping-pong kernel, removed)
 // The kernel ATTN_AUTO resolves to for a self-attention launch whose producer can fold the softmax scale into q before q is
 // rounded to bf16 (the DiT forward: qknorm_kernel's q_scale).  ATTN_W64 computes exp2(K.q) without a per-score multiply, so it
 // wants q = bf16(q_fp32 * scale * log2(e)); handing it a bf16 q to prescale itself costs a second rounding of q, which shows
-// on sharp softmax rows (large QK-norm gains) -- a raw-q ATTN_AUTO launch (the attention() seam) therefore takes ATTN_PINGPONG.
+// on sharp softmax rows (large QK-norm gains) -- a raw-q ATTN_AUTO launch (the attention() seam) therefore takes ATTN_LOCKSTEP.
 int mmpl_attention_self_variant();
 // attn_w64.hip (4 waves x 64 query rows, one wave per SIMD)
 int mmpl_attention_w64_smem();

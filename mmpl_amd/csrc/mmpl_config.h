@@ -1,0 +1,23 @@
+// Run-time switches of libmmpl_hip.so: ONE struct, filled ONCE from the environment on first use (device_state.hip), read by
+// every launcher.  They exist for A/B measurements and for the parity tests of the non-default paths (each is exercised by a
+// child-process test in tests/test_kernels_gpu.py); production runs set none of them.
+//
+//   MMPL_ATTN_V1=1               self-attention on the lock-step kernel (attn_fwd_kernel) instead of attn_w64_kernel
+//   MMPL_ATTN_NOSPLIT=1          no split-KV tail round
+//   MMPL_ATTN_NO_MERGE=1         do not merge contiguous KV pages into longer ones
+//   MMPL_CROSS_W64=1             text / image cross-attention on attn_w64_kernel
+//   MMPL_GEMM_V1=1 / _V2=1       every GEMM on the 128x128 register-staged / the 256x128 3-stage-DMA kernel
+//   MMPL_GEMM_GROUP=n            M-tile group of v6's tile order (default: per shape)
+//   MMPL_GEMM_PF=n               v6's L2 prefetch distance in k-tiles (default 2; 0 = off)
+//   MMPL_GEMM_DIRECT_EPILOGUE=1  v6 without the LDS-staged 16-byte epilogue
+//   MMPL_GEMM_STATIC_TILES=1     v6 with one block per tile instead of tile tickets
+//   MMPL_GEMM_NO_SYNC_SWEEPS=1   v6 with contiguous per-XCD chunks of the tile list instead of dealt M-groups
+#pragma once
+
+struct MmplRuntimeConfig {
+  bool attn_v1, attn_nosplit, attn_no_merge, cross_w64;
+  bool gemm_v1, gemm_v2, gemm_direct_epilogue, gemm_static_tiles, gemm_no_sync_sweeps;
+  int gemm_group;      // 0 = launcher's choice
+  int gemm_pf;         // k-tiles
+};
+const MmplRuntimeConfig& mmpl_config();

@@ -1,4 +1,4 @@
-// Helpers shared by the one-wave-per-SIMD kernels (attn_w64.hip, gemm_w64.hip): compile-time loops whose bodies are
+// Helpers shared by the one-wave-per-SIMD kernels (attn_w64.hip): compile-time loops whose bodies are
 // `asm volatile` statements with literal register numbers, and the clobber list that hands the whole accumulator file to them.
 #pragma once
 #include <type_traits>

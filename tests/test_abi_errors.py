@@ -52,6 +52,7 @@ def test_kernel_entry_points_reject_bad_shapes():
     assert _err(lib.mmpl_attn_fwd(None, 100, None, 128, kp, kp, 128, 128, 1, 64, 64, 1, 0.088, None))      # ldq % 8
     assert _err(lib.mmpl_attn_fwd(None, 128, None, 128, kp, kp, 128, 128, 25, 64, 64, 1, 0.088, None))     # > 24 pages
     assert _err(lib.mmpl_attn_fwd_variant(None, 128, None, 128, kp, kp, 128, 128, 1, 64, 64, 1, 0.088, None, 0, 9, 0, None))   # unknown kernel variant
+    assert _err(lib.mmpl_attn_fwd_variant(None, 128, None, 128, kp, kp, 128, 128, 1, 64, 64, 1, 0.088, None, 0, 2, 0, None))   # the removed ping-pong kernel
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="asserts the no-GPU failure mode")

@@ -3,7 +3,7 @@
 
     python tools/attn_dev.py check [variants...]     # edge-case shapes vs an fp32 restatement evaluated by torch on the device
     python tools/attn_dev.py bench [variants...]     # 14B/720p stage shapes, interleaved rounds, TFLOP/s per variant
-variants: 1 lock-step, 2 ping-pong, 3 w64 on a raw q, 4 w64 on a producer-prescaled q (default: 2 4)
+variants: 1 lock-step, 3 w64 on a raw q, 4 w64 on a producer-prescaled q (default: 2 4)
 """
 import ctypes as C
 import math
@@ -164,7 +164,7 @@ def cycles(stage="s3"):
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "check"
-    variants = [int(x) for x in sys.argv[2:] if x.isdigit()] or [2, 4]
+    variants = [int(x) for x in sys.argv[2:] if x.isdigit()] or [1, 4]
     stages = [x.split("=")[1].split(",") for x in sys.argv[2:] if x.startswith("stages=")]
     if what == "cycles":
         cycles(stages[0][0] if stages else "s3")

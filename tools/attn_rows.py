@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools.attn_dev import run, dev, BF  # noqa: E402
 
 Lq, H, S = (int(x) for x in sys.argv[1:4])
-variants = [int(x) for x in sys.argv[4:]] or [2, 3]
+variants = [int(x) for x in sys.argv[4:]] or [1, 3]
 assert S <= 128
 torch.manual_seed(1)
 d = H * 128

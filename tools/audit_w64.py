@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build attn_w64.hip with -save-temps in a scratch dir and audit the ISA (CDNA guide 5.7 item 4): the kernel owns a[0:255] by
 name, so the build is only valid if the compiler never touches the accumulator file itself, spills nothing and uses no scratch.
-    python tools/audit_w64.py [--src gemm_w64.hip] [--keep DIR]"""
+    python tools/audit_w64.py [--src gemm.hip] [--keep DIR]"""
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -88,7 +88,7 @@ def bench_gemm_ref(iters):
 
 
 def gemm_phases(epi=3):
-    """needs a -DGEMM_ABL=32 build: per-wave { prologue, k loop, epilogue } cycles written over the output"""
+    """needs a -DGEMM6_TIMING=1 build (tools/gemm6_phases2.sh): per-wave { prologue, k loop, epilogue } cycles written over the output"""
     M, N, K = 25200, 5120, 5120
     A = torch.randn(M, K, device=dev).to(BF)
     W = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(BF)
@@ -108,31 +108,11 @@ def gemm_phases(epi=3):
           f"p95 {t[:, 1].quantile(0.95).item():.0f})  epilogue {t[:, 2].mean().item():.0f} (max {t[:, 2].max().item():.0f}) cycles", flush=True)
 
 
-def gemm_cycles():
-    """needs a -DGEMM_ABL=16|... build of gemm_w64.hip: per-wave cycle counts of the k loop instead of C"""
-    M, N, K = 25200, 5120, 5120
-    A = torch.randn(M, K, device=dev).to(BF)
-    W = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(BF)
-    b = torch.randn(N, device=dev).to(BF)
-    Cc = torch.zeros(M, N, device=dev, dtype=BF)
-    for _ in range(3):
-        _lib.check(lib.mmpl_gemm(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(Cc), N, M, N, K, 0, None, N, None, N, 3600, _lib.stream_ptr()))
-    torch.cuda.synchronize()
-    nblk = ((M + 255) // 256) * (N // 256)
-    t = Cc.view(-1).view(torch.float32)[: nblk * 8].view(-1, 2).double()
-    t = t[t[:, 1] > 0]
-    per = t[:, 0] / t[:, 1]
-    print(f"gemmcycles M={M} N={N} K={K}: waves {len(per)} stages {t[0, 1].item():.0f} cycles/stage mean {per.mean().item():.1f} min {per.min().item():.1f} "
-          f"max {per.max().item():.1f} -> {per.mean().item() / 32:.2f} cycles per MFMA", flush=True)
-
-
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 5
     if what in ("attn", "all"):
         bench_attn(iters)
-    if what == "gemmcycles":
-        gemm_cycles()
     if what == "gemmphases":
         gemm_phases(3)
         gemm_phases(0)
