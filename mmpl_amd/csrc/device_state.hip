@@ -51,6 +51,7 @@ const MmplRuntimeConfig& mmpl_config() {
     c.gemm_static_tiles = flag("MMPL_GEMM_STATIC_TILES"); c.gemm_no_sync_sweeps = flag("MMPL_GEMM_NO_SYNC_SWEEPS");
     c.gemm_group = num("MMPL_GEMM_GROUP", 0);
     c.gemm_pf = num("MMPL_GEMM_PF", 2);
+    c.vae_no_halo = flag("MMPL_VAE_NO_HALO");
     return c;
   }();
   return cfg;

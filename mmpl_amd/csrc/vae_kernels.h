@@ -9,8 +9,11 @@ struct ConvArgs {
   int Cin, Hp, Wp;
   int st, sy, sx;      // output -> source strides (time, y, x)
   int ntaps;
+  int kt, kh, kw;      // the filter's extent (ntaps = kt * kh * kw, tap = (a * kh + b) * kw + d)
   int tap_off[27];     // pixel offset of each tap inside the padded source
   const bf16_t* W;     // [N, ntaps * Cin]
+  const bf16_t* Wfrag; // optional: the same weights packed fragment-major for conv_halo_kernel:
+                       // [Cin / 32][ntaps][ceil(N / 16)][64 lanes][8] with lane = 16 * (k chunk of 8) + (row within the 16)
   const bf16_t* bias;  // [N]
   int M, N, Ho, Wo;    // M = To * Ho * Wo output pixels
   bf16_t* dst;         // destination volume [.., Hd, Wd, ldd]; output pixel (t,y,x) -> (t+dt0, y+dy0, x+dx0), channel dc0+n

@@ -61,11 +61,28 @@ class VaeEngine:
             t = torch.cat([t, t.new_zeros(1, t.shape[1])])
         return t
 
+    @staticmethod
+    def _frag_pack(w2d: torch.Tensor, cin_pad: int) -> torch.Tensor:
+        """[N, ntaps * Cin] (tap-major, Cin a multiple of 32) -> the fragment-major packing conv_halo_kernel loads: for every
+        (32-channel chunk, tap, 16-row group) the 64 lanes' 16 bytes back to back, lane = 16 * (8-channel k chunk) + row."""
+        n, k = w2d.shape
+        ntaps, nchunk = k // cin_pad, cin_pad // 32
+        npad = (n + 15) // 16 * 16
+        if npad != n:
+            w2d = torch.cat([w2d, w2d.new_zeros(npad - n, k)])
+        return w2d.view(npad // 16, 16, ntaps, nchunk, 4, 8).permute(3, 2, 0, 4, 1, 5).contiguous().view(-1)
+
     def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
         n = self._lib.mmpl_vae_num_weights()
         ws = []
         for i in range(n):
             name = self._lib.mmpl_vae_weight_name(i).decode()
+            if name.endswith(".weight.frag"):
+                base = name[:-len(".frag")]
+                w2d = self._repack(base, sd[base])
+                cin = sd[base].shape[1]
+                ws.append(self._frag_pack(w2d, (cin + 31) // 32 * 32).to(self.device))
+                continue
             ws.append(self._repack(name, sd[name]).contiguous().to(self.device))
         arr = (C.c_void_p * n)(*[t.data_ptr() for t in ws])
         _lib.check(self._lib.mmpl_vae_bind_weights(self._h, arr, n), "mmpl_vae_bind_weights")
