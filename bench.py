@@ -55,6 +55,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=None,
                     help="ranks (one process per GPU).  Inside a torch.distributed.run launch it must equal WORLD_SIZE; outside one, "
                          "N > 1 makes this process start that launch itself (before it touches the GPU) and relay rank 0's JSON line")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI, one rank per GPU (the measured configuration).  gloo: functional runs of the N > 1 code "
+                         "paths on a box with fewer GPUs than ranks (ranks share devices, exchanges are staged through the host) -- "
+                         "the JSON line says so and is not a scaling measurement")
     ap.add_argument("--dry-run-launch", action="store_true",
                     help="launcher self-test without GPUs: every rank joins a gloo group, rank 0 prints how many ranks it saw")
     ap.add_argument("--steps", type=int, default=8)
@@ -184,8 +188,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
         # the wavefront's receives wait for whole anchor stages (minutes at 14B/720p): never the 10-minute default
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), timeout=datetime.timedelta(hours=4))
+        if args.dist_backend == "gloo":
+            local_rank %= max(torch.cuda.device_count(), 1)
+            dist.init_process_group("gloo", timeout=datetime.timedelta(hours=4))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), timeout=datetime.timedelta(hours=4))
     assert args.steps > 0 and args.warmup >= 0
+    gloo = dist is not None and args.dist_backend == "gloo"
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     pair, lanes, lane, n_lanes = None, None, rank, world
@@ -282,8 +291,12 @@ def main():
                 eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out)
         else:
             kc, vc, ck, cv = caches[0]
-            eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=st["mine"])
-            pair.exchange(st["mine"], st["flow"])
+            if st.get("fwd_graph") is not None and not eager:
+                xin(st)                                # (refreshes the 36-channel buffer of the i2v model type)
+                st["fwd_graph"].replay()               # this rank's branch: one hipGraph per forward
+            else:
+                eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=st["mine"])
+            pair.exchange(st["mine"], st["flow"])      # host-issued 2-rank all-gather: the step cannot be ONE graph here
         sched.step_cfg(st["fc"], st["fu"], 5.0, st["lat"])
         if i % 4 == 1:
             handoff_exchange(st)
@@ -295,11 +308,23 @@ def main():
             return
         handoff_send[0].copy_(st["lat"][0])
         handoff_send[1:].copy_(st["lat"])
+        nxt = rank + 1 if lanes is None else (lanes[lane + 1] if lane + 1 < n_lanes else world)
+        prv = rank - 1 if lanes is None else (lanes[lane - 1] if lane > 0 else -1)
+        if gloo:                                   # functional path: through the host, on the compute stream
+            reqs, rbuf = [], None
+            if nxt < world:
+                reqs.append(dist.isend(handoff_send.cpu(), nxt))
+            if prv >= 0:
+                rbuf = torch.empty(handoff_recv.shape, dtype=handoff_recv.dtype)
+                reqs.append(dist.irecv(rbuf, prv))
+            for w in reqs:
+                w.wait()
+            if rbuf is not None:
+                handoff_recv.copy_(rbuf)
+            return
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             ops = []
-            nxt = rank + 1 if lanes is None else (lanes[lane + 1] if lane + 1 < n_lanes else world)
-            prv = rank - 1 if lanes is None else (lanes[lane - 1] if lane > 0 else -1)
             if nxt < world:
                 ops.append(dist.P2POp(dist.isend, handoff_send, nxt))
             if prv >= 0:
@@ -315,6 +340,7 @@ def main():
         torch.cuda.synchronize()
 
     use_graph = pair is None and not args.eager           # (the CFG pair's per-step all-gather is a host-issued RCCL call)
+    graphed = not args.eager                              # some hipGraph is replayed in the timed region -> per-kernel events come from the eager pass
     if use_graph:
         for st in stage_state:                              # eager warm-up of every launch shape, then capture
             for which, out in ((0, st["fc"]), (1, st["fu"])):
@@ -333,6 +359,12 @@ def main():
                     eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out)
                 sched.step_cfg_table(st["fc"], st["fu"], st["lat"], st["t"])
             st["graph"], st["replays"] = g, 0
+    if pair is not None and not args.eager:
+        # CFG pair: each rank's forward is a hipGraph (the per-step exchange of the two flow predictions is issued by the host)
+        for st in stage_state:
+            kc, vc, ck, cv = caches[0]
+            st["t"].fill_(999.0)
+            st["fwd_graph"] = eng.capture(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, st["mine"])
     for i in range(args.warmup):
         one_step(i)
     handoff_exchange(stage_state[1])       # untimed: the p2p communicators exist before the timed region whatever --warmup is
@@ -340,7 +372,7 @@ def main():
         pair.exchange(stage_state[0]["mine"], stage_state[0]["flow"])
     torch.cuda.current_stream().wait_stream(side)
     barrier()
-    if not args.no_profile and not use_graph:
+    if not args.no_profile and not graphed:
         lib.mmpl_profile_enable(1 if args.profile_all else ((1 << 1) << 1))      # default: kind 1 = self-attention only
     # the K timed steps keep rotating through the four stage shapes; every step is also bracketed by a HIP event pair so
     # that the chunk time can be assembled per stage (exact for any K, not only multiples of 4)
@@ -357,7 +389,7 @@ def main():
     # ---- eager pass (after the timed region when that one replayed graphs): one rotation of the four stages with a hipEvent
     # pair around every self-attention launch (all kernel classes with --profile-all) -> `eager` figures and `roofline`
     eager_step_s = None
-    if use_graph:
+    if graphed:
         for st in stage_state:
             st["sched"].set_timesteps(50, shift=5.0)
         for i in range(4):
@@ -405,7 +437,7 @@ def main():
     from mmpl_amd.stage_plan import assemble_chunk_seconds
     stage_s, chunk_s = assemble_chunk_seconds(step_s, args.warmup, stage_flops)     # 4 stages x (50 denoise steps + 1 refresh pair)
     if dist is not None:
-        tt = torch.tensor([elapsed, chunk_s], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed, chunk_s], device="cpu" if gloo else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, chunk_s = tt[0].item(), tt[1].item()
 
@@ -424,12 +456,15 @@ def main():
             "n_gpus": dist.get_world_size() if dist is not None else 1,        # the ranks RCCL actually connected
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            **({"functional_only": "gloo backend: ranks share GPUs, exchanges staged through the host -- exercises the N > 1 code "
+                                   "paths, not a scaling measurement"} if gloo else {}),
             "config": {"workload": f"Wan2.1-{args.mode.upper()}-{args.model} {args.res} chunk-AR denoise step (cond+uncond DiT forward, CFG, UniPC), "
                                    f"rotating the four {args.mode.upper()} denoise stages {stage_shapes} (query, attended frames); one "
                                    f"21-latent-frame chunk per GPU = 204 step-equivalents",
                        "frame_seqlen": S, "latent_hw": [lat_h, lat_w], "sampling_steps": 50, "guidance_scale": 5.0,
                        "timed_path": ("one hipGraph replay per denoise step (2 DiT forwards + fused CFG/UniPC, device-resident step tables)"
-                                      if use_graph else "eager launches"),
+                                      if use_graph else ("one hipGraph replay per forward + host-issued flow exchange + fused CFG/UniPC launch"
+                                                         if pair is not None and not args.eager else "eager launches")),
                        "model_type": "i2v (in_dim 36 + CLIP image stream)" if args.i2v_model else "t2v",
                        "parallelism": (f"chunk-per-rank x{world}" if pair is None else f"{n_lanes} chunk lanes x 2 (cond|uncond) CFG split, "
                                        "per-step 2-rank all-gather of flow predictions") +
@@ -461,7 +496,7 @@ def main():
                 traffic_src = "profiles/r02_pmc_attention_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the shipping kernel, mean of s0..s3)"
             res["roofline"] = {"bound": "mfma", "kernel": "attn_w64_kernel (self-attention over the KV-slot page table; one op = main launch + split-KV tail launch + merge)",
                                "measured_in": ("eager pass right after the timed graph replays (hipEvent pair per launch on the launch stream)"
-                                               if use_graph else "timed region (hipEvent pair per launch on the launch stream)"),
+                                               if graphed else "timed region (hipEvent pair per launch on the launch stream)"),
                                "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
                                "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
                                "avg_launch_ms": a["ms"] / a["launches"], "launches": a["launches"],
