@@ -487,13 +487,22 @@ def main():
             a = prof["attn_self"]
             ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
             traffic, traffic_src = None, None
-            pmc = os.path.join(ROOT, "profiles", "r02_pmc_attention_hbm.json")
-            if args.model == "14B" and args.res == "720p" and os.path.exists(pmc):
-                # HBM bytes per launch cannot be collected inside this process (rocprofv3 --pmc wraps the program): the
-                # committed PMC passes of the same kernel on the same four launch shapes, averaged over the rotation
-                st = json.load(open(pmc))["stages"]
-                traffic = sum(st[k]["hbm_bytes"] for k in ("s0", "s1", "s2", "s3")) / 4.0
-                traffic_src = "profiles/r02_pmc_attention_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the shipping kernel, mean of s0..s3)"
+            if args.model == "14B" and args.res == "720p" and args.mode == "t2v":
+                # HBM bytes per launch cannot be collected inside this process (rocprofv3 --pmc wraps the program): the newest
+                # committed PMC passes.  r03+: collected on THIS command (tools/r03_profiles.sh: bench.py under rocprofv3 --pmc
+                # FETCH_SIZE / WRITE_SIZE in separate passes), mean over the rotation's self-attention ops.
+                import glob
+                cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]*_pmc_attention_hbm.json")))
+                if cands:
+                    traffic = json.load(open(cands[-1]))["mean_hbm_bytes_per_op"]
+                    traffic_src = (f"profiles/{os.path.basename(cands[-1])} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py itself, "
+                                   "mean of the rotation's self-attention ops)")
+                else:
+                    pmc = os.path.join(ROOT, "profiles", "r02_pmc_attention_hbm.json")
+                    if os.path.exists(pmc):
+                        st = json.load(open(pmc))["stages"]
+                        traffic = sum(st[k]["hbm_bytes"] for k in ("s0", "s1", "s2", "s3")) / 4.0
+                        traffic_src = "profiles/r02_pmc_attention_hbm.json (round-2 kernel, one-op helper, mean of s0..s3)"
             res["roofline"] = {"bound": "mfma", "kernel": "attn_w64_kernel (self-attention over the KV-slot page table; one op = main launch + split-KV tail launch + merge)",
                                "measured_in": ("eager pass right after the timed graph replays (hipEvent pair per launch on the launch stream)"
                                                if graphed else "timed region (hipEvent pair per launch on the launch stream)"),

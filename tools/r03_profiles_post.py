@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Post-processes what tools/r03_profiles.sh collected: python3 tools/r03_profiles_post.py <dir> <tag>
+   -> <dir>/<tag>_kernel_stats.csv, <dir>/<tag>_pmc_attention_hbm.json, <dir>/<tag>_pmc_mfma_busy.md"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+d, tag = sys.argv[1], sys.argv[2]
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    return name if len(name) <= 110 else name[:107] + "..."
+
+
+# ---- kernel stats
+for f in glob.glob(os.path.join(d, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    with open(os.path.join(d, f"{tag}_kernel_stats.csv"), "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in rows:
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+
+# ---- HBM traffic of the self-attention op, measured on the bench process itself: per counter pass, the sum over every
+# self-attention launch (main launch + split-KV tail launch + merge) divided by the number of ops (= main launches)
+S, d_model = 3600, 5120
+vals, n_ops = {}, 0
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    fs = glob.glob(os.path.join(d, f"hbm_{ctr}", "**", "*counter_collection.csv"), recursive=True)
+    if not fs:
+        continue
+    tot, ops = 0.0, 0
+    seen = set()
+    for r in csv.DictReader(open(fs[0])):
+        if r["Counter_Name"] != ctr or not ("attn_w64" in r["Kernel_Name"] or "attn_merge" in r["Kernel_Name"]):
+            continue
+        tot += float(r["Counter_Value"])
+        if "attn_w64_kernel<false>" in r["Kernel_Name"] and r["Dispatch_Id"] not in seen:
+            seen.add(r["Dispatch_Id"])
+            ops += 1
+    if ops:
+        vals[ctr] = tot / ops
+        n_ops = ops
+if len(vals) == 2:
+    rd, wr = vals["FETCH_SIZE"] * 1024 * 2, vals["WRITE_SIZE"] * 1024
+    shapes = {"s0": (2, 2), "s1": (7, 9), "s2": (6, 13), "s3": (6, 21)}
+    algo = sum(2 * (nq * S * d_model * 2) + 2 * (npg * S * d_model * 2) for nq, npg in shapes.values()) / 4.0
+    json.dump({"kernel": "attn_w64_kernel (+ split-KV tail launch + attn_merge_kernel: one attention op)",
+               "config": "Wan2.1-T2V-14B 720p, H=40, S=3600; the bench rotation s0..s3 (mean over its self-attention ops)",
+               "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 4 --warmup 0 "
+                         "--no-cpu-baseline --no-vae --no-profile --eager: the bench process itself; per op = sum over all self-attention "
+                         "launches / number of ops; bytes = KiB*1024, FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md HBM section)",
+               "ops": n_ops, "FETCH_SIZE_KiB_per_op": vals["FETCH_SIZE"], "WRITE_SIZE_KiB_per_op": vals["WRITE_SIZE"],
+               "hbm_read_bytes_per_op": rd, "hbm_write_bytes_per_op": wr, "mean_hbm_bytes_per_op": rd + wr,
+               "algorithmic_bytes_per_op": algo, "ratio": (rd + wr) / algo}, open(os.path.join(d, f"{tag}_pmc_attention_hbm.json"), "w"), indent=1)
+
+# ---- MFMA busy per kernel
+fs = glob.glob(os.path.join(d, "busy", "**", "*counter_collection.csv"), recursive=True)
+if fs:
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.Counter()
+    dur = collections.defaultdict(float)
+    seen = set()
+    for r in csv.DictReader(open(fs[0])):
+        k = short(r["Kernel_Name"])
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Dispatch_Id"] not in seen:
+            seen.add(r["Dispatch_Id"])
+            cnt[k] += 1
+            dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    lines = [f"# {tag} PMC: matrix-pipe occupancy per kernel over 4 denoise steps of `bench.py` (14B / 720p)", "",
+             "`rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 4 --warmup 0 "
+             "--no-cpu-baseline --no-vae --no-profile`", "",
+             "MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the fraction of SIMD cycles with",
+             "the matrix pipe busy at the clock the kernel actually ran at (clock = GRBM_GUI_ACTIVE / 8 / duration; counter collection",
+             "serialises kernels, so durations are not comparable with the timing runs).", "",
+             "| kernel | launches | MFMA busy | effective clock GHz | waves resident (SQ_WAVE_CYCLES x 4 / 1024 / cycles) |", "|---|---|---|---|---|"]
+    for k in sorted(acc, key=lambda k: -dur[k])[:14]:
+        a = acc[k]
+        cyc = a["GRBM_GUI_ACTIVE"] / 8
+        if cyc <= 0:
+            continue
+        lines.append(f"| `{k[:70]}` | {cnt[k]} | {100 * a['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc):.1f} % | {cyc / dur[k]:.2f} | "
+                     f"{a['SQ_WAVE_CYCLES'] * 4 / 1024 / cyc:.2f} |")
+    open(os.path.join(d, f"{tag}_pmc_mfma_busy.md"), "w").write("\n".join(lines) + "\n")
+print("post-processing done:", sorted(os.path.basename(p) for p in glob.glob(os.path.join(d, f"{tag}_*"))))
