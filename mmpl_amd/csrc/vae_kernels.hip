@@ -228,8 +228,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     read_a(a0, 0);
 #pragma unroll 1
     for (int tap = 0; tap + 1 < ntaps; tap += 2) {   // ntaps = 9 | 27 (odd): the last tap is left in (a0, w0)
-      load_w(w1, chunk, tap + 1); read_a(a1, tap + 1); mma(a0, w0);
-      load_w(w0, chunk, tap + 2); read_a(a0, tap + 2); mma(a1, w1);
+      // (the scheduling barriers pin "next step's loads first, then this step's 24 MFMAs": left alone, hipcc sinks the loads to
+      // half a step before their use and the wave waits on L2 latency every step)
+      load_w(w1, chunk, tap + 1); read_a(a1, tap + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, w0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_w(w0, chunk, tap + 2); read_a(a0, tap + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, w1);
+      __builtin_amdgcn_sched_barrier(0);
     }
     mma(a0, w0);
   }
