@@ -103,6 +103,7 @@ struct Ctx {
   bool dry;
   hipError_t err = hipSuccess;
   const char* where = "";
+  std::map<std::string, int> ring_base;   // temporal-cache rings: first slot of the two cached frames, per conv volume
   size_t plain_elems;
   bf16_t* plain(int i) { return ar.get("plain" + std::to_string(i), plain_elems); }
   void chk(hipError_t e, const char* w) { if (e != hipSuccess && err == hipSuccess) { err = e; where = w; } }
@@ -124,10 +125,11 @@ void norm_into(Ctx& c, const bf16_t* x, int T, int H, int W, int C, const bf16_t
 
 void conv(Ctx& c, const bf16_t* src, int Cin, int Hp, int Wp, int st, int sy, int sx, int kt, int kh, int kw, const bf16_t* Wt,
           const bf16_t* bias, int To, int Ho, int Wo, int N, bf16_t* dst, int Hd, int Wd, int ldd, int dt0, int dy0, int dx0,
-          const bf16_t* res, int ldres, const bf16_t* Wfrag = nullptr) {
+          const bf16_t* res, int ldres, const bf16_t* Wfrag = nullptr, const bf16_t* const* frames = nullptr, int n_frames = 0) {
   if (c.dry) return;
   ConvArgs g = {};
   g.Wfrag = Wfrag;
+  for (int j = 0; j < n_frames && j < 8; ++j) g.frame[j] = frames[j];
   g.src = src; g.Cin = Cin; g.Hp = Hp; g.Wp = Wp; g.st = st; g.sy = sy; g.sx = sx; g.ntaps = kt * kh * kw;
   g.kt = kt; g.kh = kh; g.kw = kw;
   int k = 0;
@@ -147,14 +149,38 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const bf16_t* Wt, int ldw, const bf1
 }
 
 // CausalConv3d 3x3x3 with temporal cache; input = norm+SiLU(x) (gamma != null) or x as is.
+// The cache (vae.py:14, 207-216: the conv's last two input frames) is the two frame slots in front of the T new ones.  With the
+// halo-tile kernel the Tmax + 2 slots of the volume form a RING -- logical frame j lives in slot (base + j) mod (Tmax + 2), the norm
+// pass writes the new frames straight into their slots, the kernel is handed the slot pointers, and base advances by T: no copy.
+// (The plain kernel addresses frames linearly, so there the last two frames are copied to the front after every call: 4 % of a decode.)
 void cached_conv3(Ctx& c, const std::string& name, const bf16_t* x, const bf16_t* gamma, int T, int Tmax, int H, int W, int Cin,
                   int N, bf16_t* out, const bf16_t* res) {
   const size_t slot = (size_t)(H + 2) * (W + 2) * Cin;
-  bf16_t* vol = c.ar.get(name + ".pad", (size_t)(Tmax + 2) * slot);
-  if (x) norm_into(c, x, T, H, W, Cin, gamma, gamma != nullptr, vol, H + 2, W + 2, Cin, 2, 1, 1);
+  const int Tp = Tmax + 2;
+  bf16_t* vol = c.ar.get(name + ".pad", (size_t)Tp * slot);
+  const bf16_t* Wfrag = c.v->Wopt(name + ".weight.frag");
+  bool ring = false;
+  if (x && !c.dry) {
+    ConvArgs probe = {};
+    probe.Wfrag = Wfrag; probe.kt = probe.kh = probe.kw = 3; probe.st = probe.sy = probe.sx = 1; probe.Hp = H + 2; probe.Wp = W + 2;
+    probe.Ho = H; probe.Wo = W; probe.M = T * H * W; probe.N = N; probe.Cin = Cin;
+    ring = vae_conv_uses_halo(probe);
+  }
+  if (!ring) {
+    if (x) norm_into(c, x, T, H, W, Cin, gamma, gamma != nullptr, vol, H + 2, W + 2, Cin, 2, 1, 1);
+    conv(c, vol, Cin, H + 2, W + 2, 1, 1, 1, 3, 3, 3, c.v->W(name + ".weight"), c.v->W(name + ".bias"), T, H, W, N, out, H, W, N, 0, 0, 0,
+         res, N, Wfrag);
+    copy_slots(c, vol, slot, T, 0, 2);
+    return;
+  }
+  int& base = c.ring_base[name];
+  const bf16_t* frames[8];
+  for (int j = 0; j < T + 2; ++j) frames[j] = vol + (size_t)((base + j) % Tp) * slot;
+  for (int t = 0; t < T; ++t)
+    norm_into(c, x + (size_t)t * H * W * Cin, 1, H, W, Cin, gamma, gamma != nullptr, const_cast<bf16_t*>(frames[t + 2]), H + 2, W + 2, Cin, 0, 1, 1);
   conv(c, vol, Cin, H + 2, W + 2, 1, 1, 1, 3, 3, 3, c.v->W(name + ".weight"), c.v->W(name + ".bias"), T, H, W, N, out, H, W, N, 0, 0, 0,
-       res, N, c.v->Wopt(name + ".weight.frag"));
-  copy_slots(c, vol, slot, T, 0, 2);
+       res, N, Wfrag, frames, T + 2);
+  base = (base + T) % Tp;
 }
 
 // ResidualBlock (vae.py:186-220): x [T,H,W,cin] -> out [T,H,W,cout]; x, out, tmp are distinct plain buffers

@@ -6,6 +6,8 @@
 // implicit-GEMM convolution out of a padded channels-last volume (see vae_kernels.hip)
 struct ConvArgs {
   const bf16_t* src;   // padded source volume [Tp, Hp, Wp, Cin]
+  const bf16_t* frame[8];   // optional (frame[0] != null; conv_halo_kernel only): source frame j of the volume lives HERE instead of at
+                            // src + j * Hp * Wp * Cin -- the temporal cache as a ring of frame slots instead of a shifted copy
   int Cin, Hp, Wp;
   int st, sy, sx;      // output -> source strides (time, y, x)
   int ntaps;
@@ -22,6 +24,7 @@ struct ConvArgs {
   int ldres;
 };
 hipError_t vae_launch_conv(const ConvArgs& g, hipStream_t s);
+bool vae_conv_uses_halo(const ConvArgs& g);   // will vae_launch_conv take conv_halo_kernel (the only one that understands ConvArgs.frame)?
 
 struct NormArgs {
   const bf16_t* src;   // plain [npix, C]

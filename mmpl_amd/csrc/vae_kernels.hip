@@ -201,6 +201,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
 
   const int nhalo = kt * HPIX * 4;              // 16-byte chunks of the halo image
+  // the kt source frames of this output frame: consecutive frames of the volume, or (ring mode) whatever slots the host names
+  const size_t fstride = (size_t)g.Hp * g.Wp * g.Cin;
+  const bool ring = g.frame[0] != nullptr;
+  const bf16_t* fp0 = ring ? g.frame[t0] : g.src + (size_t)t0 * fstride;
+  const bf16_t* fp1 = ring ? g.frame[t0 + (kt > 1 ? 1 : 0)] : fp0 + fstride;
+  const bf16_t* fp2 = ring ? g.frame[t0 + (kt > 2 ? 2 : 0)] : fp0 + 2 * fstride;
 #pragma unroll 1
   for (int c0 = 0; c0 < g.Cin; c0 += 32) {
     const int chunk = c0 >> 5;
@@ -215,8 +221,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int u = 0; u < 8; ++u) {
         const int q = min(tid + 256 * (8 * h + u), nhalo - 1);     // (kt = 1: the surplus slots re-fetch the last chunk -- no branches)
         const int hp = q >> 2, f = hp / HPIX, r = hp - f * HPIX, hy = r / HWD, hx = r - hy * HWD;
-        const size_t pix = ((size_t)(t0 + f) * g.Hp + min(y0 + hy, g.Hp - 1)) * g.Wp + min(x0 + hx, g.Wp - 1);
-        hv[u] = *reinterpret_cast<const u32x4*>(g.src + pix * g.Cin + c0 + (q & 3) * 8);
+        const size_t pix = (size_t)min(y0 + hy, g.Hp - 1) * g.Wp + min(x0 + hx, g.Wp - 1);
+        const bf16_t* fp = f == 0 ? fp0 : (f == 1 ? fp1 : fp2);
+        hv[u] = *reinterpret_cast<const u32x4*>(fp + pix * g.Cin + c0 + (q & 3) * 8);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -492,12 +499,17 @@ hipError_t launch_halo(const ConvArgs& g, hipStream_t s) {
 }
 }  // namespace
 
+// 3x3 (x 1 | 3) filters at stride 1 out of a volume padded by one pixel, fragment-packed weights bound, a width the kernel is built for
+bool vae_conv_uses_halo(const ConvArgs& g) {
+  return !mmpl_config().vae_no_halo && g.Wfrag != nullptr && g.kh == 3 && g.kw == 3 && (g.kt == 1 || g.kt == 3) && g.st == 1 && g.sy == 1 &&
+         g.sx == 1 && g.Hp == g.Ho + 2 && g.Wp == g.Wo + 2 && g.M > 0 && g.M % (g.Ho * g.Wo) == 0 && g.Cin % 32 == 0 && (g.N % 96 == 0 || g.N <= 16);
+}
+
 hipError_t vae_launch_conv(const ConvArgs& g, hipStream_t s) {
   if (g.M <= 0) return hipSuccess;
   if (g.Cin % 32 || g.N % 4 || g.ntaps < 1 || g.ntaps > 27) return hipErrorInvalidValue;
-  // 3x3 (x 1 | 3) filters at stride 1 out of a volume padded by one pixel: the LDS halo-tile kernel
-  if (!mmpl_config().vae_no_halo && g.Wfrag != nullptr && g.kh == 3 && g.kw == 3 && (g.kt == 1 || g.kt == 3) && g.st == 1 && g.sy == 1 && g.sx == 1 &&
-      g.Hp == g.Ho + 2 && g.Wp == g.Wo + 2 && g.M % (g.Ho * g.Wo) == 0) {
+  if (g.frame[0] != nullptr && !vae_conv_uses_halo(g)) return hipErrorInvalidValue;      // only conv_halo_kernel reads ring slots
+  if (vae_conv_uses_halo(g)) {
     if (g.N % 96 == 0) return launch_halo<6>(g, s);           // 96, 192, 384: every ResidualBlock / upsampler conv of the Wan VAE
     if (g.N <= 16) return launch_halo<1>(g, s);               // the decoder head (96 -> 3, padded to 4): one 16-column fragment
     // (a 128-wide variant spills 18 registers and a 32-wide one does not fit hipcc's allocator at all: the remaining
