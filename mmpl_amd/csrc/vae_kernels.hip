@@ -279,6 +279,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // (8 channels) per lane per pass: LG = 16 for C <= 128, 32 for C <= 256, else the whole wave with up to two passes (C <= 1024) --
 // so a wave normalises 4 / 2 / 1 pixels and every lane moves data (with one pixel per wave the C = 96 layers of the decoder's
 // full-resolution stage kept 12 of 64 lanes busy and the kernel ran at a quarter of the HBM rate: 27 % of a decode).
+#ifndef VAE_NORM_FASTDIV
+#define VAE_NORM_FASTDIV 1      // dev: 0 = the compiler's division sequences (A/B of the VALU cost)
+#endif
 template <int LG>
 __global__ __launch_bounds__(256) void norm_act_pad_kernel(NormArgs a) {
   // NB pixels per lane group and pass, all their loads issued before the first reduction: one 16-byte load per lane in flight
@@ -311,11 +314,17 @@ __global__ __launch_bounds__(256) void norm_act_pad_kernel(NormArgs a) {
     for (int it = 0; it < NIT; ++it)
 #pragma unroll
       for (int j = 0; j < 8; ++j) sq[b] += v[b][it][j] * v[b][it][j];
-    float denom = 1.f;
+    float denom = 1.f, rden = 1.f;
     if (a.gamma) {
 #pragma unroll
       for (int o = LG / 2; o > 0; o >>= 1) sq[b] += __shfl_xor(sq[b], o, 64);    // sum over the pixel's LG lanes
       denom = fmaxf(rbf(sqrtf(sq[b])), 1e-12f);                                  // torch.norm output is a bf16 tensor, clamp_min(eps)
+      // x / denom for every channel of the pixel: one reciprocal per pixel (v_rcp + a Newton step), then per element the
+      // quotient with its residual folded back -- q = x r; q += (x - q d) r -- which is the correctly rounded fp32 quotient the
+      // reference's division produces (the compiler's own division sequence is ~10 VALU instructions per element, and this
+      // kernel is VALU-bound: two divisions, three bf16 roundings and an exponential per element)
+      rden = __frcp_rn(denom);
+      rden = fmaf(fmaf(-denom, rden, 1.f), rden, rden);
     }
     if (!live[b]) continue;
     const long pix = pixb[b];
@@ -332,10 +341,19 @@ __global__ __launch_bounds__(256) void norm_act_pad_kernel(NormArgs a) {
                              bf2f(gu.z & 0xffff), bf2f(gu.z >> 16), bf2f(gu.w & 0xffff), bf2f(gu.w >> 16)};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          float n = rbf(v[b][it][j] / denom);         // x / norm      (bf16 tensor)
+#if VAE_NORM_FASTDIV
+          float q = v[b][it][j] * rden;
+          q = fmaf(fmaf(-q, denom, v[b][it][j]), rden, q);
+          float n = rbf(q);                           // x / norm      (bf16 tensor)
           n = rbf(n * a.scale);                       // * sqrt(C)
           n = rbf(n * gm[j]);                         // * gamma
+          o[j] = a.silu ? __fdividef(n, 1.0f + __expf(-n)) : n;      // (rounded to bf16 by the pack below)
+#else
+          float n = rbf(v[b][it][j] / denom);
+          n = rbf(n * a.scale);
+          n = rbf(n * gm[j]);
           o[j] = a.silu ? silu(n) : n;
+#endif
         }
       } else {
 #pragma unroll
