@@ -299,43 +299,31 @@ int mmpl_attention_self_variant() { return mmpl_config().attn_v1 ? ATTN_LOCKSTEP
 
 namespace {
 // Pages that lie back to back in memory (the KV-cache slots of one layer are one allocation; so are a stage's scratch pages) are
-// presented to the kernel as fewer, longer pages: every page ends in a ragged 64-row tile (3600 = 56 * 64 + 16, 1560 = 24 * 64 + 24)
-// whose MFMAs mostly multiply masked rows -- 1.3 % of the tiles at 720p, 2.5 % at 480p.  The kernel takes ONE page length, so
-// the maximal runs are cut into pages of gcd(run lengths) x page_rows (s0: 2 slots -> 1 page; s2: 13 -> 1; s3: 15 + 6 -> 7
-// pages of 3; s1's 4 + 5 stay 9).  Softmax does not care about the order of the keys; only fp32 summation order changes.
+// presented to attn_w64_kernel as fewer, longer pages: every page ends in a ragged 64-row tile (3600 = 56 * 64 + 16, 1560 =
+// 24 * 64 + 24) whose MFMAs mostly multiply masked rows -- 1.3 % of the tiles at 720p, 2.5 % at 480p.  The kernel takes a row
+// count per page (AttnArgs.page_rows_each), so every maximal run becomes ONE page (s0: 2 slots -> 1 page; s1: 4 + 5 -> 2;
+// s2: 13 -> 1; s3: 15 + 6 -> 2).  Softmax does not care about the order of the keys; only fp32 summation order changes.
 AttnArgs merge_contiguous_pages(const AttnArgs& a) {
   int order[MMPL_MAX_PAGES];
   for (int i = 0; i < a.n_pages; ++i) order[i] = i;
   for (int i = 1; i < a.n_pages; ++i)                      // insertion sort by K address
     for (int j = i; j > 0 && a.k_pages[order[j]] < a.k_pages[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
   const size_t kstride = (size_t)a.page_rows * a.ldk, vstride = (size_t)a.page_rows * a.ldv;
-  int run_start[MMPL_MAX_PAGES], run_len[MMPL_MAX_PAGES], n_runs = 0, g = 0;
+  // (the kernel addresses a page with 32-bit byte offsets / a buffer descriptor: a merged page stays below 2 GiB)
+  const size_t per_page = 2 * (kstride > vstride ? kstride : vstride);
+  const int max_run = per_page ? (int)(((1ull << 31) - 1) / per_page) : 1;
+  AttnArgs m = a;
+  m.n_pages = 0;
   for (int i = 0; i < a.n_pages;) {
     int r = 1;
-    while (i + r < a.n_pages && a.k_pages[order[i + r]] == a.k_pages[order[i + r - 1]] + kstride &&
+    while (i + r < a.n_pages && r < max_run && a.k_pages[order[i + r]] == a.k_pages[order[i + r - 1]] + kstride &&
            a.v_pages[order[i + r]] == a.v_pages[order[i + r - 1]] + vstride)
       ++r;
-    run_start[n_runs] = i; run_len[n_runs++] = r;
-    int x = g, y = r;
-    while (y) { const int t = x % y; x = y; y = t; }
-    g = x;
+    m.k_pages[m.n_pages] = a.k_pages[order[i]];
+    m.v_pages[m.n_pages] = a.v_pages[order[i]];
+    m.page_rows_each[m.n_pages++] = r * a.page_rows;
     i += r;
   }
-  // (the kernels address a page with 32-bit byte offsets / buffer descriptors)
-  while (g > 1 && ((size_t)g * kstride * 2 >= (1ull << 31) || (size_t)g * vstride * 2 >= (1ull << 31))) {
-    int d = 2;
-    while (g % d) ++d;
-    g /= d;
-  }
-  if (g <= 1) return a;
-  AttnArgs m = a;
-  m.page_rows = a.page_rows * g;
-  m.n_pages = 0;
-  for (int r = 0; r < n_runs; ++r)
-    for (int j = 0; j < run_len[r]; j += g) {
-      m.k_pages[m.n_pages] = a.k_pages[order[run_start[r] + j]];
-      m.v_pages[m.n_pages++] = a.v_pages[order[run_start[r] + j]];
-    }
   return m;
 }
 }  // namespace
@@ -345,7 +333,9 @@ hipError_t mmpl_launch_attention(const AttnArgs& a_in, hipStream_t s) {
   if (a_in.n_pages <= 0 || a_in.n_pages > MMPL_MAX_PAGES) return hipErrorInvalidValue;
   const bool no_merge = mmpl_config().attn_no_merge;
   const bool w64_bound = a_in.variant == ATTN_W64 || (a_in.variant == ATTN_AUTO && !a_in.cross && a_in.q_prescaled && mmpl_attention_self_variant() == ATTN_W64);
-  const AttnArgs a = (!no_merge && w64_bound && a_in.n_pages > 1) ? merge_contiguous_pages(a_in) : a_in;
+  AttnArgs a = a_in;
+  for (int p = 0; p < a.n_pages; ++p) a.page_rows_each[p] = a.page_rows;
+  if (!no_merge && w64_bound && a.n_pages > 1) a = merge_contiguous_pages(a);
   if (a.n_pages <= 0 || a.n_pages > MMPL_MAX_PAGES || a.page_rows <= 0 || (a.ldq % 8) || (a.ldk % 8) || (a.ldv % 8) ||
       (a.ldo % 4) || (a.variant != ATTN_AUTO && a.variant != ATTN_LOCKSTEP && a.variant != ATTN_W64))
     return hipErrorInvalidValue;
@@ -375,7 +365,8 @@ hipError_t mmpl_launch_attention(const AttnArgs& a_in, hipStream_t s) {
   // XCD would run alone for a whole block time.  They are launched instead as `sp` blocks each over 1/sp of the KV tiles
   // (fp32 partials in split_ws) followed by a small merge kernel, so the tail round lasts ~1/sp block times.
   const int per_xcd = mmpl_cus_per_xcd();
-  const int tiles = a.n_pages * ((a.page_rows + KVB - 1) / KVB);
+  int tiles = 0;
+  for (int p = 0; p < a.n_pages; ++p) tiles += (a.page_rows_each[p] + KVB - 1) / KVB;
   int sp = 1, tb = 0, b = 0;
   if (!no_split && a.split_ws && (a.H & 7) == 0) {
     b = n_qb * (a.H / 8);

@@ -75,11 +75,12 @@ struct Ctx {
   int hi;
   // ---- wave-uniform state
   const bf16_t* const* k_pages; const bf16_t* const* v_pages;
-  int ldk, ldv, page_rows, head, T;
+  int ldk, ldv, head, T;
+  const int* rows_each;                        // rows of every page (kernel argument array)
   u32x4 ksrd, vsrd;                            // buffer descriptors of the cursors' pages (this head's 256-byte column)
   uint32_t ksoff, vsoff, tile_bytes_k, tile_bytes_v;   // byte offset of the cursor tile's first row within its page
   uint32_t kstep, vstep;                       // what an iteration adds to ksoff / vsoff: the tile's bytes, 0 once parked
-  int t_first, tiles_pp, masked;               // masked: M is not all zero
+  int t_first, masked;                         // masked: M is not all zero
   uint32_t kslot, vslot;                       // LDS address of this wave's piece 0 in the slot the cursor tile goes to
   uint32_t rk, rv;                             // ring offsets of the tiles the next B phase reads (K(j+1), V(j))
   int first[2];                                // GENERAL pass: stream has not finished its first tile yet
@@ -166,16 +167,29 @@ struct Ctx {
   // between runs, places both cursors for iteration j from scratch (K at tile j + 4, V at j + 3, each parked on the block's last
   // tile once it gets there -- that tile is simply re-fetched, so every event issues exactly 8 pieces and the counted waits
   // never change), sets or clears the mask tile for tile j, and returns how many iterations may run before the next event.
-  MMPL_DEV void seek_k(int t, int& pos) {
-    const int at = t_first + t, pg = at / tiles_pp;
-    pos = at - pg * tiles_pp;
-    ksrd = page_srd(k_pages[pg], head, page_rows, ldk);
+  // tile index `at` of the block's page list -> its page, the tile's index inside the page, the page's tile count (pages may
+  // differ in length: merged runs of cache slots; <= 24 pages, scalar code that runs between runs only)
+  MMPL_DEV void locate(int at, int& pg, int& pos, int& tiles_pg) const {
+    pg = 0;
+    int start = 0, tp = (rows_each[0] + KVB - 1) / KVB;
+    while (at >= start + tp) {
+      start += tp;
+      ++pg;
+      tp = (rows_each[pg] + KVB - 1) / KVB;
+    }
+    pos = at - start;
+    tiles_pg = tp;
+  }
+  MMPL_DEV void seek_k(int t, int& pos, int& tiles_pg) {
+    int pg;
+    locate(t_first + t, pg, pos, tiles_pg);
+    ksrd = page_srd(k_pages[pg], head, rows_each[pg], ldk);
     ksoff = (uint32_t)pos * tile_bytes_k;
   }
-  MMPL_DEV void seek_v(int t, int& pos) {
-    const int at = t_first + t, pg = at / tiles_pp;
-    pos = at - pg * tiles_pp;
-    vsrd = page_srd(v_pages[pg], head, page_rows, ldv);
+  MMPL_DEV void seek_v(int t, int& pos, int& tiles_pg) {
+    int pg;
+    locate(t_first + t, pg, pos, tiles_pg);
+    vsrd = page_srd(v_pages[pg], head, rows_each[pg], ldv);
     vsoff = (uint32_t)pos * tile_bytes_v;
   }
   MMPL_DEV void set_mask(int valid) {
@@ -199,22 +213,23 @@ struct Ctx {
     masked = 0;
   }
   MMPL_DEV int plan(int j) {
-    int n = T - j, pos;
+    int n = T - j, pos, tp;
     const int tk = min(j + 4, T - 1), tv = min(j + 3, T - 1);
-    seek_k(tk, pos);
+    seek_k(tk, pos, tp);
     kstep = 0;
-    if (tk < T - 1) { kstep = tile_bytes_k; n = min(n, min(tiles_pp - pos, T - tk)); }
-    seek_v(tv, pos);
+    if (tk < T - 1) { kstep = tile_bytes_k; n = min(n, min(tp - pos, T - tk)); }
+    seek_v(tv, pos, tp);
     vstep = 0;
-    if (tv < T - 1) { vstep = tile_bytes_v; n = min(n, min(tiles_pp - pos, T - tv)); }
-    const int valid = page_rows - (tiles_pp - 1) * KVB;                  // rows of a page's last tile
-    const int pos_j = (t_first + j) % tiles_pp;
-    if (valid < KVB && pos_j == tiles_pp - 1) {
+    if (tv < T - 1) { vstep = tile_bytes_v; n = min(n, min(tp - pos, T - tv)); }
+    int pg_j, pos_j, tp_j;
+    locate(t_first + j, pg_j, pos_j, tp_j);
+    const int valid = rows_each[pg_j] - (tp_j - 1) * KVB;                // rows of this page's last tile
+    if (valid < KVB && pos_j == tp_j - 1) {
       set_mask(valid);
       n = 1;
     } else {
       if (masked) clear_mask();
-      if (valid < KVB) n = min(n, tiles_pp - 1 - pos_j);
+      n = min(n, (valid < KVB ? tp_j - 1 : tp_j) - pos_j);               // a run ends with tile j's page (before its ragged last tile)
     }
     return __builtin_amdgcn_readfirstlane(n);
   }
@@ -320,14 +335,14 @@ template <int MODE> MMPL_DEV void w64_pass(Ctx& k) {
   k.kstep = k.vstep = 0;
 
   // ---- prologue: DMA events -4 .. -1 (event e = { K(e+4), V(e+3) }; V(-1) does not exist), then the K(0) fragments
-  int pos;
-  k.seek_k(0, pos);
+  int pos, tpg;
+  k.seek_k(0, pos, tpg);
   sfor<4>([&k](auto kk) { k.template dma_k<decltype(kk)::value>(); });
   k.advance_k();
 #pragma unroll 1
   for (int e = 1; e < 4; ++e) {
-    k.seek_k(min(e, T - 1), pos);
-    k.seek_v(min(e - 1, T - 1), pos);
+    k.seek_k(min(e, T - 1), pos, tpg);
+    k.seek_v(min(e - 1, T - 1), pos, tpg);
     sfor<4>([&k](auto kk) { k.template dma_k<decltype(kk)::value>(); });
     sfor<4>([&k](auto kk) { k.template dma_v<decltype(kk)::value>(); });
     k.advance_k();
@@ -420,18 +435,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
   }
 
-  const int tiles_pp = (a.page_rows + KVB - 1) / KVB;
-  const int T_all = a.n_pages * tiles_pp;
+  int T_all = 0;
+  for (int p = 0; p < a.n_pages; ++p) T_all += (a.page_rows_each[p] + KVB - 1) / KVB;
   const int t_first = SPLIT ? (int)((long long)part * T_all / sp) : 0;
   const int T = SPLIT ? (int)((long long)(part + 1) * T_all / sp) - t_first : T_all;     // tiles of THIS block
 
   Ctx k;
   k.hi = hi;
   k.k_pages = a.k_pages; k.v_pages = a.v_pages;
-  k.ldk = a.ldk; k.ldv = a.ldv; k.page_rows = a.page_rows; k.head = head; k.T = T;
+  k.ldk = a.ldk; k.ldv = a.ldv; k.rows_each = a.page_rows_each; k.head = head; k.T = T;
   k.drow = lane >> 4; k.dchunk = lane & 15;
   k.prow = 16 * wave + k.drow;                        // LDS row of piece 4w; piece 4w + k: + 4 k
-  k.t_first = t_first; k.tiles_pp = tiles_pp;
+  k.t_first = t_first;
   k.tile_bytes_k = (uint32_t)KVB * a.ldk * 2u;
   k.tile_bytes_v = (uint32_t)KVB * a.ldv * 2u;
   k.wave_slot = wave * 4096;

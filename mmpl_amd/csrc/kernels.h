@@ -47,6 +47,7 @@ struct AttnArgs {
   const bf16_t* v_pages[MMPL_MAX_PAGES];
   int ldk, ldv;
   int n_pages, page_rows;
+  int page_rows_each[MMPL_MAX_PAGES];   // attn_w64_kernel only, filled by mmpl_launch_attention: rows of page p (merged runs of slots differ in length)
   int Lq, H;
   float scale;                     // softmax scale (1/sqrt(128))
   int cross;                       // 1: text cross-attention launch (symbol tag only)
