@@ -115,7 +115,7 @@ class WanFPSWrapper(torch.nn.Module):
         if disk_sd is not None:
             self.engine.load_state_dict(disk_sd)
         self.model_type = self.engine.model_type
-        self._clip_src = None                 # the clip_fea tensor the engine's image K/V were built from
+        self._clip_src = None                 # (clip_fea tensor, its version counter) the engine's image K/V were built from
         self.uniform_timestep = not is_causal
         self.scheduler = FlowMatchScheduler(shift=timestep_shift, sigma_min=0.0, extra_one_step=True)
         self.scheduler.set_timesteps(1000, training=True)
@@ -149,10 +149,11 @@ class WanFPSWrapper(torch.nn.Module):
         y = conditional_dict.get("y") if y is None else y
         if clip_fea is None or y is None:
             raise ValueError("WanFPSWrapper: an i2v model needs clip_fea and y (model.py:672-673)")
-        if clip_fea is not self._clip_src:
+        key = (clip_fea, clip_fea._version)       # same tensor object AND not written in place since: the K/V are still its
+        if self._clip_src is None or self._clip_src[0] is not key[0] or self._clip_src[1] != key[1]:
             fea = clip_fea[0] if clip_fea.dim() == 3 else clip_fea
             self.engine.set_image_kv(*self.engine.precompute_image_context(fea))
-            self._clip_src = clip_fea
+            self._clip_src = key
         yy = y[0] if isinstance(y, (list, tuple)) or y.dim() == 5 else y              # [20, F, h, w]
         assert yy.shape[0] == self.engine.in_dim - 16 and yy.shape[2:] == (self.engine.lat_h, self.engine.lat_w), tuple(yy.shape)
         # (a stack of views: no host-built index tensor, so this also runs inside a hipGraph capture)
