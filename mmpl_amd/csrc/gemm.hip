@@ -679,11 +679,13 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
   GemmArgs g2 = g;
   const MmplRuntimeConfig& rc = mmpl_config();
   const int env_group = rc.gemm_group;
-  // M-tile group of the block order (how many row panels the tiles in flight on an XCD span).  Sweep with the sweep-synchronous
-  // order, nt stores and tile tickets on the 14B / 720p block shapes (TFLOP/s at group 2 / 3 / 4 / 8, profiles/r03d_*): qkv
-  // N=15360 1418 / 1431 / 1425 / 1397, ffn0 N=13824 1351 / 1360 / 1379 / 1338, o N=5120 1294 / 1336 / 1307 / 1317, ffn2 K=13824
-  // 1320 / 1312 / 1307 / 1313; M=7200 and 8192^3 prefer 4.
-  g2.group = env_group > 0 ? env_group : (g.M >= 16384 ? (g.N >= 8192 ? 4 : (g.K >= 8192 ? 2 : 3)) : 4);
+  // M-tile group of the block order (how many row panels the tiles in flight on an XCD span).  Sweeps with the sweep-synchronous
+  // order, nt stores and tile tickets on the 14B / 720p block shapes (TFLOP/s at group 2 / 3 / 4 / 8; profiles/r03d_*, r03C_*):
+  //   M = 25200 (99 row panels): qkv 1418 / 1431 / 1425 / 1397, ffn0 1351 / 1360 / 1379 / 1338, o 1294 / 1336 / 1307 / 1317, ffn2 1320 / 1312 / 1307 / 1313
+  //   M = 21600 (85 row panels): qkv 1372 / 1394 / 1413, ffn0 1298 / 1329 / 1321, o 1271 / 1284 / 1301, ffn2 1321 / 1312 / 1365
+  // -> 4, except the narrow (N < 8192) GEMMs when the row panels divide into groups of 3: 3, or 2 for the long-K one.
+  const int tiles_m_ = (g.M + BM3 - 1) / BM3;
+  g2.group = env_group > 0 ? env_group : ((g.M >= 16384 && g.N < 8192 && tiles_m_ % 3 == 0) ? (g.K >= 8192 ? 2 : 3) : 4);
   // the 16-byte epilogue needs 8-element alignment of everything it touches; otherwise the direct 8-byte one
   const bool env_direct = rc.gemm_direct_epilogue;
   // (strides AND base pointers: mmpl_gemm is public ABI and callers hand in views such as a column-offset C)

@@ -51,8 +51,9 @@ def bench_attn(iters):
 
 
 def bench_gemm(iters):
-    for name, M, N, K, epi in (("qkv", 25200, 15360, 5120, 0), ("o", 25200, 5120, 5120, 3), ("ffn0", 25200, 13824, 5120, 1),
-                               ("ffn2", 25200, 5120, 13824, 3), ("qkv_s0", 7200, 15360, 5120, 0), ("sq8k", 8192, 8192, 8192, 0)):
+    m_big = int(os.environ.get("BENCH_M", "25200"))          # the stage's query rows: 25200 (s1), 21600 (s2, s3)
+    for name, M, N, K, epi in (("qkv", m_big, 15360, 5120, 0), ("o", m_big, 5120, 5120, 3), ("ffn0", m_big, 13824, 5120, 1),
+                               ("ffn2", m_big, 5120, 13824, 3), ("qkv_s0", 7200, 15360, 5120, 0), ("sq8k", 8192, 8192, 8192, 0)):
         # BENCH_PAD_K / BENCH_PAD_N: extra elements in the leading dimension of the K-contiguous operands / of C and the residual
         # (dev: does the power-of-two-ish row stride camp on a few HBM channels?)
         pk, pn = int(os.environ.get("BENCH_PAD_K", "0")), int(os.environ.get("BENCH_PAD_N", "0"))
