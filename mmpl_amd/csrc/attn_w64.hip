@@ -1,6 +1,6 @@
 // Self-attention forward, 64 query rows per wave: 4 waves x 64 rows, ONE wave per SIMD, the whole 512-entry register file.
 //
-// Same math, page table, LDS images and fragment layouts as attn_pp_kernel (attention.hip; replaces attention.py:139-185 + the
+// Same math, page table and fragment layouts as attn_fwd_kernel (attention.hip; replaces attention.py:139-185 + the
 // K/V gather of causal_fps_model.py:219-227), but every K / V fragment read from LDS feeds TWO MFMAs (the wave's two 32-row
 // query blocks "A" and "B"), so LDS fragment traffic and LDS-DMA pieces per MFMA are half of the 8 x 32-row kernels'.
 //
