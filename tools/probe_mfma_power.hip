@@ -11,7 +11,7 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-template <int SHAPE>
+template <int SHAPE, int ORDER>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void mfma_loop(const bf16x8* in, float* out, int iters) {
   const int lane = threadIdx.x & 63;
   bf16x8 a[4], b[4];
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(i + u) & 3], b[i & 3], acc[i], 0, 0, 0);
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ORDER == 2 ? a[0] : ORDER == 1 ? a[u] : a[(i + u) & 3], ORDER == 2 ? b[0] : b[i & 3], acc[i], 0, 0, 0);
     }
     for (int i = 0; i < 8; ++i) for (int j = 0; j < 16; ++j) r += acc[i][j];
   } else {
@@ -42,13 +42,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (lane == 0 && blockIdx.x == 0) out[1 + (threadIdx.x >> 6)] = r;
 }
 
-template <int SHAPE> void run(const bf16x8* in, float* out, const char* name) {
+template <int SHAPE, int ORDER = 0> void run(const bf16x8* in, float* out, const char* name) {
   const int blocks = 256 * 4, iters = 4000;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 3; ++rep) {
     hipEventRecord(e0);
-    for (int k = 0; k < 5; ++k) hipLaunchKernelGGL(mfma_loop<SHAPE>, dim3(blocks), dim3(256), 0, 0, in, out, iters);
+    for (int k = 0; k < 5; ++k) mfma_loop<SHAPE, ORDER><<<dim3(blocks), dim3(256)>>>(in, out, iters);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -70,5 +70,12 @@ int main(int argc, char** argv) {
   run<16>(in, out, "v_mfma_f32_16x16x32_bf16");
   run<32>(in, out, "v_mfma_f32_32x32x16_bf16");
   run<16>(in, out, "v_mfma_f32_16x16x32_bf16");
+  // operand stationarity (does the operand bus toggling cost power?): A and B both change every instruction (above) vs A held for 8
+  // consecutive MFMAs vs both held
+  run<32, 1>(in, out, "32x32x16, A held for 8 MFMAs");
+  run<32, 2>(in, out, "32x32x16, A and B held");
+  run<32, 0>(in, out, "32x32x16, both change");
+  run<32, 1>(in, out, "32x32x16, A held for 8 MFMAs");
+  run<32, 2>(in, out, "32x32x16, A and B held");
   return 0;
 }
