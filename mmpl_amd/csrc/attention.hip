@@ -257,7 +257,8 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnArgs a, int local_b
   __shared__ float wgt[QB][4];
   const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
   const int n_qb = (a.Lq + QB - 1) / QB;
-  const int local = local_base + k, head = xcd + 8 * (local / n_qb), qb = local % n_qb;
+  int head, qb;
+  if (!mmpl_attn_item(a.H, n_qb, xcd, local_base + k, head, qb)) return;
   const float* base = a.split_ws + (size_t)(xcd * tb + k) * sp * (QB * 130);
   const float c = a.scale * 1.4426950408889634f;
   {
@@ -367,15 +368,18 @@ hipError_t mmpl_launch_attention(const AttnArgs& a_in, hipStream_t s) {
   const int per_xcd = mmpl_cus_per_xcd();
   int tiles = 0;
   for (int p = 0; p < a.n_pages; ++p) tiles += (a.page_rows_each[p] + KVB - 1) / KVB;
-  int sp = 1, tb = 0, b = 0;
-  if (!no_split && a.split_ws && (a.H & 7) == 0) {
-    b = n_qb * (a.H / 8);
-    tb = b % per_xcd;
-    if (b > per_xcd && tb > 0 && per_xcd / tb >= 2) sp = per_xcd / tb > 4 ? 4 : per_xcd / tb;
+  // b = work items per XCD (kernels.h: mmpl_attn_item), tb = those of the partial last round.  Only a tail that fits ONE round of
+  // parts is split (tb * sp <= CUs per XCD): tails of 3 shorter rounds (tb = 17 -> 3 parts, 23-24 -> 4) and launches with fewer
+  // items than CUs measured 0.6-8 % SLOWER than leaving them alone (profiles/r03Q_*).
+  const int total = n_qb * a.H;
+  const int b = (a.H & 7) == 0 ? total / 8 : (total + 7) / 8, tb = b % per_xcd;
+  int sp = 1;
+  if (!no_split && a.split_ws && b > per_xcd && tb > 0 && per_xcd / tb >= 2) {
+    sp = per_xcd / tb > 4 ? 4 : per_xcd / tb;
     if (tiles / sp < 8 || (size_t)8 * tb * sp * QB * 130 * sizeof(float) > a.split_ws_bytes) sp = 1;
   }
   if (sp == 1) {
-    run((a.H & 7) == 0 ? n_qb * a.H : 8 * ((n_qb * a.H + 7) / 8), 0, 1, false);        // other head counts: grid padded to 8 XCD chunks
+    run(8 * b, 0, 1, false);
   } else {
     run(8 * (b - tb), 0, 1, false);
     run(8 * tb * sp, b - tb, sp, true);

@@ -383,27 +383,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   const int n_qb = (a.Lq + QB - 1) / QB;
   int head, qb, part = 0, tail_idx = 0;
-  if (SPLIT) {
+  {
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    part = idx % sp;
-    tail_idx = idx / sp;
-    const int local = local_base + tail_idx;
-    head = xcd + 8 * (local / n_qb);
-    qb = local % n_qb;
-    tail_idx = xcd * (gridDim.x / (8 * sp)) + tail_idx;
-  } else if ((a.H & 7) == 0) {
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    head = xcd + 8 * (local / n_qb);
-    qb = local % n_qb;
-  } else {
-    // any other head count (Wan 1.3B: 12): the hardware deals blocks round-robin to the 8 XCDs, so XCD x is given the x-th
-    // contiguous chunk of the head-major (head, query block) list -- the blocks sharing one L2 work on at most a few heads;
-    // the grid is padded to 8 chunks (launcher), the padding blocks leave at once
-    const int total = n_qb * a.H, per = (total + 7) >> 3;
-    const int item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (item >= total) return;
-    head = item / n_qb;
-    qb = item % n_qb;
+    int local = idx;
+    if (SPLIT) {
+      part = idx % sp;
+      tail_idx = idx / sp;
+      local = local_base + tail_idx;
+      tail_idx = xcd * (gridDim.x / (8 * sp)) + tail_idx;
+    }
+    if (!mmpl_attn_item(a.H, n_qb, xcd, local, head, qb)) return;     // grid padding (head counts that are no multiple of 8)
   }
 
   // the accumulator file is ours: this statement makes the kernel descriptor allocate all 256 entries

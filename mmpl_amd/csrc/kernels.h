@@ -55,6 +55,22 @@ struct AttnArgs {
   int variant;                     // ATTN_* kernel selector (0 = auto)
   int q_prescaled;                 // q was already multiplied by scale * log2(e) by its producer (ATTN_W64 only)
 };
+// Work item `local` of XCD `xcd` -> (head, query block) for attn_w64_kernel / attn_merge_kernel (the hardware deals workgroups
+// round-robin to the 8 XCDs: blockIdx & 7).  H % 8 == 0: XCD x owns heads x, x+8, ...; any other head count (Wan 1.3B: 12):
+// XCD x owns the x-th contiguous chunk of ceil(n_qb*H / 8) items of the head-major (head, query block) list, so the blocks
+// sharing one L2 work on at most a few heads; false = past the end of the list (the last XCD's chunk can be short).
+__device__ __forceinline__ bool mmpl_attn_item(int H, int n_qb, int xcd, int local, int& head, int& qb) {
+  if ((H & 7) == 0) {
+    head = xcd + 8 * (local / n_qb);
+    qb = local % n_qb;
+    return head < H;
+  }
+  const int total = n_qb * H, per = (total + 7) >> 3, item = xcd * per + local;
+  if (local >= per || item >= total) return false;
+  head = item / n_qb;
+  qb = item % n_qb;
+  return true;
+}
 enum { ATTN_AUTO = 0, ATTN_LOCKSTEP = 1, ATTN_W64 = 3 };      // (2 was the round-1 ping-pong kernel, removed)
 // The kernel ATTN_AUTO resolves to for a self-attention launch whose producer can fold the softmax scale into q before q is
 // rounded to bf16 (the DiT forward: qknorm_kernel's q_scale).  ATTN_W64 computes exp2(K.q) without a per-score multiply, so it

@@ -302,6 +302,40 @@ def test_attention_split_kv_tail_round(lib, variant):
     assert rel_l2(o_ws, o_plain) < 3e-3
 
 
+# (H, query blocks, rows per page): 12 heads (Wan 1.3B: no multiple of the 8 XCDs -- 65 items per XCD, one tail item each in 4
+# parts; the last XCD's chunk is short, so its tail item does not exist); 20 heads: 73 items per XCD, a tail of 9 in 3 parts each
+@pytest.mark.parametrize("H,n_qb,S,max_tail_items", [(12, 43, 704, 8), (20, 29, 704, 8 * 9)])
+def test_attention_split_kv_tail_any_shape(lib, H, n_qb, S, max_tail_items):
+    from mmpl_amd import _lib
+    from oracle import wan_dit_ref as W
+    torch.manual_seed(13)
+    dev = "cuda:0"
+    n_pages, Lq = 3, 256 * n_qb - 57
+    d = H * 128
+    c = (1.0 / math.sqrt(128)) * 1.4426950408889634
+    q = (torch.randn(Lq, d, device=dev) * c).to(BF)                      # variant 4: q prescaled by its producer
+    kc = torch.randn(n_pages * S, d, device=dev).to(BF)
+    vc = torch.randn(n_pages * S, d, device=dev).to(BF)
+    kp = (C.c_void_p * n_pages)(*[kc[i * S:].data_ptr() for i in range(n_pages)])
+    vp = (C.c_void_p * n_pages)(*[vc[i * S:].data_ptr() for i in range(n_pages)])
+    o_ws = torch.full((Lq, d), float("nan"), device=dev, dtype=BF)
+    o_plain = torch.full((Lq, d), float("nan"), device=dev, dtype=BF)
+    ws = torch.empty(lib.mmpl_attn_workspace_bytes(), dtype=torch.uint8, device=dev)
+    _lib.check(lib.mmpl_attn_fwd_variant(_lib.ptr(q), d, _lib.ptr(o_ws), d, kp, vp, d, d, n_pages, S, Lq, H, 1.0 / math.sqrt(128),
+                                         _lib.ptr(ws), ws.numel(), 4, 0, _sp()))
+    _lib.check(lib.mmpl_attn_fwd_variant(_lib.ptr(q), d, _lib.ptr(o_plain), d, kp, vp, d, d, n_pages, S, Lq, H, 1.0 / math.sqrt(128),
+                                         None, 0, 4, 0, _sp()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(o_ws.float()).all() and torch.isfinite(o_plain.float()).all()      # every (row, head) was written by both
+    diff = (o_ws != o_plain).reshape(Lq, H, 128).any(dim=2)               # [row, head]: went through the split path
+    n_items = int(diff.reshape(-1, H)[: (Lq // 256) * 256].reshape(-1, 256, H).any(dim=1).sum()) + int(diff[(Lq // 256) * 256:].any(dim=0).sum())
+    assert 0 < n_items <= max_tail_items, n_items
+    assert rel_l2(o_ws, o_plain) < 3e-3
+    rows = torch.unique(torch.cat([torch.arange(0, 200), diff.any(dim=1).nonzero()[:, 0][::7].cpu(), torch.arange(Lq - 200, Lq)]))[:1500]
+    ref32 = W.sdpa_fp32(q[rows].float().div(c).reshape(1, -1, H, 128).cpu(), kc.reshape(1, -1, H, 128).cpu(), vc.reshape(1, -1, H, 128).cpu()).reshape(-1, d)
+    assert rel_l2(o_ws[rows], ref32) < 1e-2 and rel_l2(o_plain[rows], ref32) < 1e-2
+
+
 @pytest.mark.parametrize("variant", [4])
 def test_attention_split_kv_tail_round_spiked(lib, variant):
     """The tail round with scores no FAST pass can hold: a few keys are large multiples of a few queries, in the rows of the
