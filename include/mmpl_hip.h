@@ -106,6 +106,17 @@ int mmpl_gemm(const void* A, int lda, const void* W, int ldw, const void* bias, 
 int mmpl_gemm_tickets(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N, int K,
                       int epi, const void* res, int ldres, const void* gate, int gate_frame_stride, int rows_per_frame,
                       void* tile_counter, mmpl_stream_t stream);
+/* mmpl_gemm_tickets + a split-K launch for the partial last round of tiles (a GEMM of R * 256 + t tiles on 256 CUs otherwise takes
+ * R + 1 rounds however small t is: the Wan 1.3B block GEMMs, every model's 2-frame stage): when the leftover tiles fit one round in
+ * 2-4 parts each, they are computed as that many blocks over a share of K each, fp32 partials in `scratch`, summed in part order by
+ * the part that finishes last (deterministic), which then runs the ordinary epilogue.  scratch: mmpl_gemm_scratch_bytes() device
+ * bytes whose first 2048 are zero when a launch starts (every launch leaves them zero): [8 tile tickets | pad to 256 B | 256 tile
+ * counters | pad to 2048 B | partials].  Launches sharing a scratch must be stream-ordered.  (mmpl_dit_forward keeps one in its
+ * workspace.) */
+size_t mmpl_gemm_scratch_bytes(void);
+int mmpl_gemm_scratch(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N, int K,
+                      int epi, const void* res, int ldres, const void* gate, int gate_frame_stride, int rows_per_frame,
+                      void* scratch, size_t scratch_bytes, mmpl_stream_t stream);
 
 /* WanLayerNorm (+ per-frame modulation or affine) (wan/modules/model.py:89-99, causal_fps_model.py:343,352,355) */
 int mmpl_layernorm(const void* x, int ldx, void* y, int ldy, int rows, int d, float eps, const void* scale,

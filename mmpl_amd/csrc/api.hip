@@ -143,6 +143,7 @@ int mmpl_dit_create(const MmplDitConfig* cfg, MmplDit** out) {
     return fail("mmpl_dit_create", "unsupported dims");
   if (cfg->lat_h % 2 || cfg->lat_w % 2 || cfg->max_frames < 1 || cfg->max_frames > 8 || (cfg->in_dim != 16 && cfg->in_dim != 36) || cfg->out_dim != 16)
     return fail("mmpl_dit_create", "unsupported geometry");
+  mmpl_xcd_dispatch_ok(true);          // once per device, here because forwards may run inside a stream capture (device_state.hip)
   MmplDit* h = new MmplDit();
   h->cfg = *cfg;
   h->gh = cfg->lat_h / 2;
@@ -207,7 +208,9 @@ struct Carver {
 };
 struct FwdWs {
   bf16_t *x, *xn, *big, *attn, *ksc, *vsc, *patch, *sinu, *t1, *e, *se, *e0, *emod, *emod_head, *yh;
-  int* tile_counter;     // 8 ints: the per-XCD tile tickets of the large GEMMs (GemmArgs.tile_counter), zeroed at the start of a forward
+  int* tile_counter;     // 8 ints: the per-XCD tile tickets of the large GEMMs (GemmArgs.tile_counter), zeroed at the start of a forward;
+                         // ints 64..319: the split-K tile counters (GemmArgs.splitk_cnt)
+  float* splitk;         // fp32 partials of the GEMMs' split-K tail launch (mmpl_gemm_splitk_ws_bytes())
   size_t bytes;
 };
 FwdWs carve_fwd(const MmplDit* h, int nF, void* base) {
@@ -216,7 +219,7 @@ FwdWs carve_fwd(const MmplDit* h, int nF, void* base) {
   const size_t bigw = (size_t)(3 * c.dim > c.ffn_dim ? 3 * c.dim : c.ffn_dim);
   Carver k(base);
   FwdWs w;
-  w.tile_counter = (int*)k.take(128);     // first: the same place for every stage shape, so no other shape's activations ever land on it
+  w.tile_counter = (int*)k.take(64 + 512);     // first: the same place for every stage shape, so no other shape's activations ever land on it
   w.x = k.take(Lq * d);
   w.xn = k.take(Lq * d);
   w.big = k.take(Lq * bigw);
@@ -232,14 +235,18 @@ FwdWs carve_fwd(const MmplDit* h, int nF, void* base) {
   w.emod = k.take((size_t)c.num_layers * nF * 6 * d);
   w.emod_head = k.take((size_t)nF * 2 * d);
   w.yh = k.take(Lq * 64);
+  w.splitk = (float*)k.take(mmpl_gemm_splitk_ws_bytes() / sizeof(bf16_t));
   w.bytes = k.off;
   return w;
 }
 
 int gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, bf16_t* C, int ldc, int M, int N, int K,
-         int epi, const bf16_t* res, int ldres, const bf16_t* gate, int gfs, int rpf, hipStream_t s, int* tile_counter = nullptr) {
+         int epi, const bf16_t* res, int ldres, const bf16_t* gate, int gfs, int rpf, hipStream_t s, int* tile_counter = nullptr,
+         float* splitk_ws = nullptr) {
   GemmArgs g{A, lda, W, ldw, bias, C, ldc, M, N, K, epi, res, ldres, gate, gfs, rpf > 0 ? rpf : 1, 1.0f, 0, 0, 0, 0, 0};
   g.tile_counter = tile_counter;
+  g.splitk_ws = splitk_ws;                               // with the forward's scratch: counters 64 ints behind the tile tickets
+  g.splitk_cnt = splitk_ws ? tile_counter + 64 : nullptr;
   ProfScope ps(K_GEMM, 2.0 * M * (double)N * K, s);
   hipError_t e = mmpl_launch_gemm(g, s);
   if (e != hipSuccess) return fail("gemm", hipGetErrorString(e));
@@ -311,7 +318,7 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
   hipStream_t s = (hipStream_t)stream;
   const int S = h->S, d = c.dim, f = c.ffn_dim, Lq = nF * S, H = c.num_heads, T = c.text_len;
 
-  HIP_TRY(mmpl_launch_zero_ints(w.tile_counter, 8, s), "tile counter");                  // left zero by every GEMM that uses it
+  HIP_TRY(mmpl_launch_zero_ints(w.tile_counter, 64 + 256, s), "tile counter");                  // left zero by every GEMM that uses it
   int* const tc = w.tile_counter;
   // ---- embeddings (causal_fps_model.py:757-776)
   HIP_TRY(mmpl_launch_patchify((const bf16_t*)x_in, w.patch, h->pe_k, nF, c.in_dim, c.lat_h, c.lat_w, s), "patchify");
@@ -351,6 +358,7 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
       g.v_col0 = 2 * d;
       g.v_ld = d;
       g.tile_counter = tc;
+      g.splitk_ws = w.splitk; g.splitk_cnt = tc + 64;
       ProfScope ps(K_GEMM, 2.0 * Lq * 3.0 * d * d, s);
       HIP_TRY(mmpl_launch_gemm(g, s), "qkv gemm");
     }
@@ -389,14 +397,14 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
       ProfScope ps(K_ATTN_SELF, 4.0 * Lq * (double)np * S * d, s);
       HIP_TRY(mmpl_launch_attention(a, s), "self attention");
     }
-    TRY(gemm(w.attn, d, h->Lw(l, L_O_W), d, h->Lw(l, L_O_B), w.x, d, Lq, d, d, EPI_GATE_RES, w.x, d, em + 2 * d, 6 * d, S, s, tc));
+    TRY(gemm(w.attn, d, h->Lw(l, L_O_W), d, h->Lw(l, L_O_B), w.x, d, Lq, d, d, EPI_GATE_RES, w.x, d, em + 2 * d, 6 * d, S, s, tc, w.splitk));
     // -- cross attention (causal_fps_model.py:352-353, model.py:161-194)
     {
       LnArgs a{w.x, d, w.xn, d, Lq, d, c.eps, nullptr, nullptr, 0, S, h->Lw(l, L_N3_W), h->Lw(l, L_N3_B)};
       ProfScope ps(K_LAYERNORM, 0, s);
       HIP_TRY(mmpl_launch_layernorm(a, s), "norm3");
     }
-    TRY(gemm(w.xn, d, h->Lw(l, L_CQ_W), d, h->Lw(l, L_CQ_B), w.big, d, Lq, d, d, EPI_BIAS, nullptr, 0, nullptr, 0, 1, s, tc));
+    TRY(gemm(w.xn, d, h->Lw(l, L_CQ_W), d, h->Lw(l, L_CQ_B), w.big, d, Lq, d, d, EPI_BIAS, nullptr, 0, nullptr, 0, 1, s, tc, w.splitk));
     {
       ProfScope ps(K_QKNORM, 0, s);
       HIP_TRY(mmpl_launch_rmsnorm(w.big, d, h->Lw(l, L_CNQ), Lq, d, c.eps, s, cross_w64 ? scale * 1.4426950408889634f : 0.f), "cross q norm");
@@ -423,15 +431,15 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
         HIP_TRY(mmpl_launch_add(w.attn, w.ksc, (size_t)Lq * d, s), "x + img_x");
       }
     }
-    TRY(gemm(w.attn, d, h->Lw(l, L_CO_W), d, h->Lw(l, L_CO_B), w.x, d, Lq, d, d, EPI_RES, w.x, d, nullptr, 0, 1, s, tc));
+    TRY(gemm(w.attn, d, h->Lw(l, L_CO_W), d, h->Lw(l, L_CO_B), w.x, d, Lq, d, d, EPI_RES, w.x, d, nullptr, 0, 1, s, tc, w.splitk));
     // -- FFN (causal_fps_model.py:354-360)
     {
       LnArgs a{w.x, d, w.xn, d, Lq, d, c.eps, em + 4 * d, em + 3 * d, 6 * d, S, nullptr, nullptr};
       ProfScope ps(K_LAYERNORM, 0, s);
       HIP_TRY(mmpl_launch_layernorm(a, s), "norm2");
     }
-    TRY(gemm(w.xn, d, h->Lw(l, L_F0_W), d, h->Lw(l, L_F0_B), w.big, f, Lq, f, d, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 1, s, tc));
-    TRY(gemm(w.big, f, h->Lw(l, L_F2_W), f, h->Lw(l, L_F2_B), w.x, d, Lq, d, f, EPI_GATE_RES, w.x, d, em + 5 * d, 6 * d, S, s, tc));
+    TRY(gemm(w.xn, d, h->Lw(l, L_F0_W), d, h->Lw(l, L_F0_B), w.big, f, Lq, f, d, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 1, s, tc, w.splitk));
+    TRY(gemm(w.big, f, h->Lw(l, L_F2_W), f, h->Lw(l, L_F2_B), w.x, d, Lq, d, f, EPI_GATE_RES, w.x, d, em + 5 * d, 6 * d, S, s, tc, w.splitk));
   }
   // ---- head + unpatchify (causal_fps_model.py:384-395, 1007-1030)
   {
@@ -494,6 +502,25 @@ int mmpl_gemm_tickets(const void* A, int lda, const void* W, int ldw, const void
   if ((epi == EPI_GATE_RES && (!res || !gate)) || (epi == EPI_RES && !res)) return fail("mmpl_gemm", "missing epilogue operand");
   return gemm((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (bf16_t*)C, ldc, M, N, K, epi,
               (const bf16_t*)res, ldres, (const bf16_t*)gate, gate_frame_stride, rows_per_frame, (hipStream_t)stream, (int*)tile_counter);
+}
+
+size_t mmpl_gemm_scratch_bytes(void) { return 2048 + mmpl_gemm_splitk_ws_bytes(); }
+
+int mmpl_gemm_scratch(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N, int K,
+                      int epi, const void* res, int ldres, const void* gate, int gate_frame_stride, int rows_per_frame,
+                      void* scratch, size_t scratch_bytes, mmpl_stream_t stream) {
+  if (epi < EPI_BIAS || epi > EPI_F32_SCALE) return fail("mmpl_gemm", "unknown epilogue");
+  if ((epi == EPI_GATE_RES && (!res || !gate)) || (epi == EPI_RES && !res)) return fail("mmpl_gemm", "missing epilogue operand");
+  if (!scratch || scratch_bytes < mmpl_gemm_scratch_bytes()) return fail("mmpl_gemm_scratch", "scratch missing or smaller than mmpl_gemm_scratch_bytes()");
+  if (reinterpret_cast<uintptr_t>(scratch) % 256) return fail("mmpl_gemm_scratch", "scratch must be 256-byte aligned");
+  {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing((hipStream_t)stream, &st);
+    mmpl_xcd_dispatch_ok(st == hipStreamCaptureStatusNone);          // the once-per-device probe synchronises: never inside a capture
+  }
+  return gemm((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (bf16_t*)C, ldc, M, N, K, epi,
+              (const bf16_t*)res, ldres, (const bf16_t*)gate, gate_frame_stride, rows_per_frame, (hipStream_t)stream, (int*)scratch,
+              (float*)((char*)scratch + 2048));
 }
 
 int mmpl_layernorm(const void* x, int ldx, void* y, int ldy, int rows, int d, float eps, const void* scale,

@@ -11,7 +11,46 @@ namespace {
 std::mutex g_mu;
 std::set<std::pair<int, const void*>> g_attr_done;
 int g_per_xcd[64];
+int g_xcd_dispatch[64];      // 0 = not probed yet, 1 = workgroup b of a launch runs on XCD b & 7, -1 = it does not
+
+// every workgroup reports the XCC it runs on (HW_REG_XCC_ID[3:0])
+__global__ void xcc_probe_kernel(int* out) {
+  if (threadIdx.x == 0) {
+    int x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+    out[blockIdx.x] = x;
+  }
+}
 }  // namespace
+
+// Workgroups of a launch are dealt round-robin to the 8 XCDs.  The tile / head orders only rely on that for L2 locality, but the
+// split-K GEMM launch relies on it for VISIBILITY (the parts of a tile exchange fp32 partials through their XCD's L2 without a
+// device-scope write-back), so it is checked on the hardware, once per device, outside any stream capture (mmpl_dit_create,
+// mmpl_gemm_scratch); until / unless the check has passed, no GEMM is split.
+bool mmpl_xcd_dispatch_ok(bool may_probe) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_xcd_dispatch[dev] == 0 && may_probe) {
+    constexpr int n = 2048;
+    int* d = nullptr;
+    int h[n];
+    bool ok = hipMalloc(&d, n * sizeof(int)) == hipSuccess;
+    if (ok) {
+      hipLaunchKernelGGL(xcc_probe_kernel, dim3(n), dim3(64), 0, 0, d);
+      ok = hipMemcpy(h, d, n * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+      (void)hipFree(d);
+    }
+    unsigned seen = 0;
+    for (int x = 0; ok && x < 8; ++x) {
+      ok = !(seen & (1u << h[x]));                              // 8 residues, 8 different XCCs
+      seen |= 1u << h[x];
+    }
+    for (int b = 8; ok && b < n; ++b) ok = h[b] == h[b & 7];
+    g_xcd_dispatch[dev] = ok ? 1 : -1;
+  }
+  return g_xcd_dispatch[dev] == 1;
+}
 
 hipError_t mmpl_dyn_smem_once(const void* func, int bytes) {
   int dev = 0;
@@ -49,6 +88,7 @@ const MmplRuntimeConfig& mmpl_config() {
     c.cross_w64 = flag("MMPL_CROSS_W64");
     c.gemm_v1 = flag("MMPL_GEMM_V1"); c.gemm_v2 = flag("MMPL_GEMM_V2"); c.gemm_direct_epilogue = flag("MMPL_GEMM_DIRECT_EPILOGUE");
     c.gemm_static_tiles = flag("MMPL_GEMM_STATIC_TILES"); c.gemm_no_sync_sweeps = flag("MMPL_GEMM_NO_SYNC_SWEEPS");
+    c.gemm_no_splitk = flag("MMPL_GEMM_NO_SPLITK");
     c.gemm_group = num("MMPL_GEMM_GROUP", 0);
     c.gemm_pf = num("MMPL_GEMM_PF", 2);
     c.vae_no_halo = flag("MMPL_VAE_NO_HALO");

@@ -319,7 +319,7 @@ hipError_t mmpl_launch_unpatchify(const bf16_t* y, int ldy, bf16_t* out, int F, 
   return hipGetLastError();
 }
 __global__ void zero_ints_kernel(int* p, int n) {
-  if ((int)threadIdx.x < n) p[threadIdx.x] = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
 }
 // a kernel rather than hipMemsetAsync: inside a captured hipGraph it is an ordinary kernel node, ordered like every other launch
 // (a memset NODE was seen to run unordered under rocprofv3's kernel tracing: garbage tile tickets -> faults / hangs)

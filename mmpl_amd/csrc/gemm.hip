@@ -481,7 +481,12 @@ MMPL_DEV void gemm_epilogue_staged(const GemmArgs& g, const f32x4 (&acc)[2][4][4
 #ifndef GEMM6_TIMING
 #define GEMM6_TIMING 0      // dev: 1 = every wave leaves { prologue, k loop, epilogue } shader cycles over the output (tools/bench_kernels.py gemmphases)
 #endif
-template <int EPI>
+// SPLITK = true: the second launch of a GEMM whose tile count leaves a partial last round of one-tile-per-CU (launch_v6).  The main
+// launch stops at the last full round of every XCD's list; here each leftover tile is computed by `splitk_s` blocks over 1/s of the
+// k-tiles each.  Every part leaves its fp32 accumulators in splitk_ws (lane-private layout, fully coalesced) and draws a ticket of
+// the tile's counter; whoever draws the LAST one sums all parts IN PART ORDER (so the result does not depend on who was last) and
+// runs the ordinary epilogue.
+template <int EPI, bool SPLITK = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_v6_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   [[maybe_unused]] unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
@@ -496,7 +501,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // Ticket protocol: exactly chunk + (blocks of the XCD) tickets are drawn per launch; whoever draws the last one knows every
   // other block of the XCD is leaving and zeroes the counter for the next launch.
   __shared__ int s_ticket;
-  const bool persistent = g.tile_counter != nullptr;
+  const bool persistent = !SPLITK && g.tile_counter != nullptr;
   const int my_xcd = blockIdx.x & 7;
   const int GROUP = g.group;
   const int per_group = GROUP * tiles_n;
@@ -511,10 +516,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int dealt = rounds * per_group;                              // tiles per XCD that come from dealt groups
   const int left = nwg - 8 * dealt;                                  // tiles of the remainder list
   const int lq = left >> 3, lr = left & 7;
-  const int chunk = dealt + lq + (my_xcd < lr ? 1 : 0);
+  const int chunk_all = dealt + lq + (my_xcd < lr ? 1 : 0);
+  const int chunk_main = g.splitk_s > 1 ? chunk_all - chunk_all % g.splitk_per : chunk_all;   // the tail belongs to the split-K launch
+  const int chunk = SPLITK ? chunk_all : chunk_main;
+  [[maybe_unused]] int part = 0, slot = 0;
   const int blocks_x = (int)(gridDim.x >> 3) + (my_xcd < (int)(gridDim.x & 7) ? 1 : 0);
   for (;;) {
   int idx = blockIdx.x >> 3;                                         // index into THIS XCD's tile list (block b of a one-block-per-tile
+  if constexpr (SPLITK) {
+    const int t_local = idx / g.splitk_s;
+    part = idx - t_local * g.splitk_s;
+    slot = my_xcd * g.splitk_tb + t_local;
+    idx = chunk_main + t_local;
+    if (idx >= chunk) return;
+  }
   if (persistent) {                                                  // launch runs on XCD b & 7: the hardware deals blocks round-robin)
     if (threadIdx.x == 0) s_ticket = atomicAdd(g.tile_counter + my_xcd, 1);
     __syncthreads();
@@ -543,8 +558,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   // ---- DMA (group A only): wave w issues pieces 4q + w, q = 0..15 (q < 8: A rows 8*(4q+w).., q >= 8: W rows)
   const int prow = lane >> 3, lc = ((lane & 7) ^ (prow & 7)) << 3;   // row within the piece, swizzled source chunk (elements)
-  const bf16_t* a_k = g.A;                                         // advance by BK4 elements per tile
-  const bf16_t* w_k = g.W;
+  const int nt_all = g.K / BK4;
+  const int kt0 = SPLITK ? part * nt_all / g.splitk_s : 0;          // this block's k-tiles: [kt0, kt0 + nt)
+  const int nt = SPLITK ? (part + 1) * nt_all / g.splitk_s - kt0 : nt_all;
+  const bf16_t* const A_k0 = g.A + (size_t)kt0 * BK4;
+  const bf16_t* const W_k0 = g.W + (size_t)kt0 * BK4;
+  const bf16_t* a_k = A_k0;                                        // advance by BK4 elements per tile
+  const bf16_t* w_k = W_k0;
   auto issue_piece = [&](int q, char* st) {
     const bool isw = q >= 8;
     const int p = 4 * (q & 7) + wave;                              // piece of the A (or W) tile: rows 8p .. 8p+7
@@ -567,7 +587,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int i = 0; i < 8; ++i) a_off[i] = swz64(128 * wm + 16 * i + frow, fchunk);
 #pragma unroll
   for (int i = 0; i < 4; ++i) w_off[i] = A4_BYTES + swz64(64 * wn + 16 * i + frow, fchunk);
-  const int nt = g.K / BK4;
   // L2 prefetch shares (see the loop): wave-uniform scalars
   const bool pf_on = g.pf_dist > 0 && grp == 1 && gsz >= 2;
   const int pf_P = 32 / gsz;
@@ -598,8 +617,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int l = (wave - 4) * 64 + lane;
       char* dump = smem + 2 * STAGE4 + (wave - 4) * 256;
       const size_t koff = (size_t)(t + g.pf_dist) * BK4;
-      if (l < pf_nw) glds4s(g.W + koff, (uint32_t)(min(pf_wrow0 + (l >> 1), g.N - 1) * g.ldw + (l & 1) * 32) * 2u, dump);
-      if (l < pf_na) glds4s(g.A + koff, (uint32_t)(min(pf_arow0 + (l >> 1), g.M - 1) * g.lda + (l & 1) * 32) * 2u, dump);
+      if (l < pf_nw) glds4s(W_k0 + koff, (uint32_t)(min(pf_wrow0 + (l >> 1), g.N - 1) * g.ldw + (l & 1) * 32) * 2u, dump);
+      if (l < pf_na) glds4s(A_k0 + koff, (uint32_t)(min(pf_arow0 + (l >> 1), g.M - 1) * g.lda + (l & 1) * 32) * 2u, dump);
     }
     const char* st = smem + (t & 1) * STAGE4;
     char* nx = smem + ((t + 1) & 1) * STAGE4;
@@ -645,6 +664,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (grp == 0 || t + 1 < nt) __builtin_amdgcn_s_barrier();
   }
   if constexpr (GEMM6_TIMING) tk2 = __builtin_readcyclecounter();
+  if constexpr (SPLITK) {
+    // partial of this k range: register r of lane l of wave w at ((part slot * 8 + w) * 32 + r) * 64 + l (16 bytes each)
+    const size_t part_floats = (size_t)8 * 32 * 64 * 4;
+    f32x4* wsp = reinterpret_cast<f32x4*>(g.splitk_ws + ((size_t)slot * g.splitk_s + part) * part_floats) + (size_t)wave * 32 * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) wsp[r * 64] = acc[r >> 4][(r >> 2) & 3][r & 3];
+    // Every part of a tile runs on the tile's XCD (slot lists are per XCD, blocks are dealt round-robin: mmpl_xcd_dispatch_ok()
+    // checks that once per device), so the partials only have to reach THAT L2: stores are write-through and acknowledged by the
+    // L2 (vmcnt), the ticket is an L2 atomic, and this CU has not read the partial area in this launch (one block per CU, L1
+    // invalidated at the dispatch).  A device-scope fence here would write back the whole L2 -- measured: +60 us per GEMM.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the partial stores (and group B's prefetch DMAs into this block's LDS)
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(g.splitk_cnt + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != g.splitk_s - 1) return;                         // block-uniform
+    if (threadIdx.x == 0) g.splitk_cnt[slot] = 0;                    // every other part of the tile has left: zero for the next launch
+    const f32x4* rsp = reinterpret_cast<const f32x4*>(g.splitk_ws + (size_t)slot * g.splitk_s * part_floats) + (size_t)wave * 32 * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) acc[r >> 4][(r >> 2) & 3][r & 3] = rsp[r * 64];
+    for (int p = 1; p < g.splitk_s; ++p) {
+      rsp += part_floats / 4;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        const f32x4 v = rsp[r * 64];
+        f32x4& a = acc[r >> 4][(r >> 2) & 3][r & 3];
+        a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+      }
+    }
+  }
   if constexpr (GEMM6_ABL & 2) {
     if (g.M < 0) gemm_epilogue<EPI>(g, acc[0], m0 + 128 * wm, n0 + 64 * wn, frow, fchunk);      // keeps the accumulators alive
   } else if (EPI != EPI_F32_SCALE && g.staged_epilogue) {
@@ -675,6 +723,7 @@ template <int EPI>
 hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
   constexpr int smem = 2 * STAGE4 + 1024;        // ring + the L2 prefetch's dump area
   if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v6_kernel<EPI>), smem); e != hipSuccess) return e;
+  if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v6_kernel<EPI, true>), smem); e != hipSuccess) return e;
   const int tiles = ((g.M + BM3 - 1) / BM3) * ((g.N + BN3 - 1) / BN3);
   GemmArgs g2 = g;
   const MmplRuntimeConfig& rc = mmpl_config();
@@ -704,7 +753,33 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
   g2.pf_dist = rc.gemm_pf;
   g2.sync_sweeps = !rc.gemm_no_sync_sweeps;
   if (rc.gemm_static_tiles) g2.tile_counter = nullptr;
-  const int n_cu = 8 * mmpl_cus_per_xcd();
+  const int per = mmpl_cus_per_xcd(), n_cu = 8 * per;
+  // Split-K launch for the partial last round.  With one tile per CU a GEMM of R * 256 + t tiles takes R + 1 rounds however small t
+  // is (Wan 1.3B at 480p: 43 x 6 = 258 tiles for o / ffn2 at s1, 78 at s0; 14B / 720p s0: 580).  When every XCD's leftover (its
+  // list length mod 32, same arithmetic as the kernel) fits one round in s >= 2 parts, the main launch stops at the full rounds and
+  // the leftover tiles run as s blocks each over 1/s of K.  s <= 4: the last part to arrive reads all s partials (256 KiB each)
+  // alone.  Only for K >= 4096: the few blocks of the tail launch stream their operands alone (no neighbours sharing the L2 lines)
+  // at about half the usual rate and the partials' round trip is ~15 us, so short-K GEMMs lose (K = 1536: -9...-23 %; K = 5120:
+  // +1...+10 %; K = 8960 / 13824: +14...+58 %, profiles/r03S_gemm_splitk_micro.log).
+  g2.splitk_s = 1; g2.splitk_tb = 0; g2.splitk_per = per;
+  if (g2.tile_counter && g.splitk_ws && g.splitk_cnt && !rc.gemm_no_splitk && EPI != EPI_F32_SCALE && g.K / BK4 >= 64 && mmpl_xcd_dispatch_ok(false)) {
+    const int tiles_n_ = (g.N + BN3 - 1) / BN3, per_group = g2.group * tiles_n_;
+    const int dealt = g2.sync_sweeps ? ((tiles_m_ / g2.group) >> 3) * per_group : 0, left = tiles - 8 * dealt;
+    int tb = 0, main_tiles = 0;
+    for (int x = 0; x < 8; ++x) {
+      const int chunk = dealt + (left >> 3) + (x < (left & 7) ? 1 : 0);
+      tb = chunk % per > tb ? chunk % per : tb;
+      main_tiles += chunk - chunk % per;
+    }
+    int sp = tb > 0 ? per / tb : 1;
+    sp = sp > 4 ? 4 : sp;
+    if (sp >= 2 && (size_t)8 * tb * sp * (BM3 * BN3 * sizeof(float)) <= mmpl_gemm_splitk_ws_bytes()) {
+      g2.splitk_s = sp; g2.splitk_tb = tb;
+      if (main_tiles > 0) hipLaunchKernelGGL(gemm_bf16_v6_kernel<EPI>, dim3(main_tiles < n_cu ? main_tiles : n_cu), dim3(512), smem, s, g2);
+      hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, true>), dim3(8 * tb * sp), dim3(512), smem, s, g2);
+      return hipGetLastError();
+    }
+  }
   const int blocks = g2.tile_counter && tiles > n_cu ? n_cu : tiles;
   if (blocks == tiles) g2.tile_counter = nullptr;             // one round or less: nothing to balance
   hipLaunchKernelGGL(gemm_bf16_v6_kernel<EPI>, dim3(blocks), dim3(512), smem, s, g2);
@@ -738,6 +813,8 @@ hipError_t launch(const GemmArgs& g, hipStream_t s) {
 }
 
 }  // namespace
+
+size_t mmpl_gemm_splitk_ws_bytes() { return (size_t)256 * BM3 * BN3 * sizeof(float); }   // <= one part per CU
 
 hipError_t mmpl_launch_gemm(const GemmArgs& g, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0) return hipSuccess;

@@ -35,7 +35,13 @@ struct GemmArgs {
   int* tile_counter;
   int pf_dist;                   // v6: L2 prefetch distance in k-tiles (0 = off; set by the launcher)
   int sync_sweeps;               // v6: deal whole M-groups to the XCDs so that all of them sweep W's column panels together (set by the launcher)
+  // v6, optional (needs tile_counter too): scratch for the split-K launch of the partial last round of tiles (gemm.hip).
+  // splitk_ws: mmpl_gemm_splitk_ws_bytes() of fp32 partials; splitk_cnt: 256 device ints, zero when a launch starts and left zero.
+  float* splitk_ws; int* splitk_cnt;
+  int splitk_s, splitk_tb, splitk_per;   // set by the launcher: parts per tile (1 = no split), tail tiles per XCD (max), CUs per XCD
 };
+size_t mmpl_gemm_splitk_ws_bytes();
+bool mmpl_xcd_dispatch_ok(bool may_probe);   // device_state.hip: workgroup b runs on XCD b & 7 (probed once per device, never inside a capture)
 hipError_t mmpl_launch_gemm(const GemmArgs& g, hipStream_t s);
 
 // ---------------------------------------------------------------- attention (attention.hip)
@@ -128,7 +134,7 @@ hipError_t mmpl_launch_patchify(const bf16_t* x, bf16_t* a, int lda, int F, int 
 hipError_t mmpl_launch_add(bf16_t* a, const bf16_t* b, size_t n, hipStream_t s);
 hipError_t mmpl_launch_unpatchify(const bf16_t* y, int ldy, bf16_t* out, int F, int C, int h, int w, hipStream_t s);
 // sinusoidal timestep embedding (fp64 math): t[F] fp32 -> out[F, freq_dim] bf16 ([cos | sin])
-hipError_t mmpl_launch_zero_ints(int* p, int n, hipStream_t s);      // n <= 64
+hipError_t mmpl_launch_zero_ints(int* p, int n, hipStream_t s);
 hipError_t mmpl_launch_sinusoid(const float* t, bf16_t* out, int F, int freq_dim, hipStream_t s);
 hipError_t mmpl_launch_silu(const bf16_t* x, bf16_t* y, size_t n, hipStream_t s);
 

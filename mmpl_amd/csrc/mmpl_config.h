@@ -12,12 +12,13 @@
 //   MMPL_GEMM_DIRECT_EPILOGUE=1  v6 without the LDS-staged 16-byte epilogue
 //   MMPL_GEMM_STATIC_TILES=1     v6 with one block per tile instead of tile tickets
 //   MMPL_GEMM_NO_SYNC_SWEEPS=1   v6 with contiguous per-XCD chunks of the tile list instead of dealt M-groups
+//   MMPL_GEMM_NO_SPLITK=1        v6 without the split-K launch for the partial last round of tiles
 //   MMPL_VAE_NO_HALO=1           every VAE convolution on the plain implicit-GEMM kernel (no LDS halo tile)
 #pragma once
 
 struct MmplRuntimeConfig {
   bool attn_v1, attn_nosplit, attn_no_merge, cross_w64;
-  bool gemm_v1, gemm_v2, gemm_direct_epilogue, gemm_static_tiles, gemm_no_sync_sweeps;
+  bool gemm_v1, gemm_v2, gemm_direct_epilogue, gemm_static_tiles, gemm_no_sync_sweeps, gemm_no_splitk;
   int gemm_group;      // 0 = launcher's choice
   int gemm_pf;         // k-tiles
   bool vae_no_halo;

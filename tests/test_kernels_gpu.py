@@ -71,6 +71,56 @@ def test_cross_attention_on_w64_opt_in():
     assert " passed" in r.stdout
 
 
+# (M, N, K, epi, split): 258 tiles = one full round + 2 (Wan 1.3B ffn2 at s1); 78 tiles, no full round at all (1.3B s0); 580 = 2 rounds
+# + 68 (14B / 720p s0) with GELU and with the plain bias epilogue; NOT split: a short K (the partials' round trip costs more than it
+# saves), a leftover of 28 tiles per XCD
+@pytest.mark.parametrize("M,N,K,epi,split", [(10920, 1536, 8960, 3, True), (3120, 1536, 8960, 3, True), (7200, 5120, 5120, 1, True),
+                                             (7200, 5120, 4096, 0, True), (10920, 1536, 1536, 3, False), (9360, 1536, 8960, 4, False)])
+def test_gemm_split_k_tail(lib, M, N, K, epi, split):
+    """mmpl_gemm_scratch: the leftover tiles of the partial last round run as 2-4 blocks each over a share of K, fp32 partials summed
+    in part order by the last part to finish.  Against fp32 like test_gemm; against mmpl_gemm only the split tiles differ (fp32
+    summation order), everything else bit-identical; two runs bit-identical (deterministic); scratch header left zero."""
+    from mmpl_amd import _lib
+    torch.manual_seed(M + N + K)
+    dev = "cuda:0"
+    A = torch.randn(M, K, device=dev).to(BF)
+    W = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(BF)
+    b = (torch.randn(N, device=dev) * 0.1).to(BF)
+    res = torch.randn(M, N, device=dev).to(BF)
+    gate = torch.randn((M + 1559) // 1560, N, device=dev).to(BF)
+    plain = torch.empty(M, N, device=dev, dtype=BF)
+    _lib.check(lib.mmpl_gemm(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(plain), N, M, N, K, epi, _lib.ptr(res), N, _lib.ptr(gate), N, 1560, _sp()))
+    nb = lib.mmpl_gemm_scratch_bytes()
+    scratch = torch.zeros(nb, dtype=torch.uint8, device=dev)
+    scratch[2048:] = 0xFF                                        # the partial area needs no initialisation (NaN patterns)
+    outs = []
+    for _ in range(2):
+        out = torch.full((M, N), float("nan"), device=dev, dtype=BF)
+        _lib.check(lib.mmpl_gemm_scratch(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(out), N, M, N, K, epi, _lib.ptr(res), N,
+                                         _lib.ptr(gate), N, 1560, _lib.ptr(scratch), nb, _sp()))
+        torch.cuda.synchronize()
+        assert int(scratch[:2048].to(torch.int32).sum()) == 0
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    out = outs[0]
+    assert torch.isfinite(out.float()).all()
+    tiles_differ = (out != plain).reshape(-1)[: (M // 256) * 256 * N].reshape(M // 256, 256, N // 256, 256).any(dim=3).any(dim=1)
+    if split:
+        assert 0 < int(tiles_differ.sum()) <= 128
+    else:
+        assert torch.equal(out, plain)
+    y = A.float() @ W.float().t() + b.float()
+    y = y.to(BF).float()
+    if epi == 1:
+        y = torch.nn.functional.gelu(y, approximate="tanh")
+    if epi == 3:
+        fr = torch.arange(M, device=dev) // 1560
+        y = res.float() + (y * gate.float()[fr]).to(BF).float()
+    if epi == 4:
+        y = res.float() + y
+    assert rel_l2(out, y.to(BF)) < 2e-3 and rel_l2(out, plain) < 1e-3
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(25200, 5120, 1024, 3), (9000, 2560, 512, 0), (4096, 5120, 5120, 1), (3120, 768, 256, 4)])
 def test_gemm_dynamic_tile_scheduling(lib, M, N, K, epi):
     """mmpl_gemm_tickets: the large-problem kernel launched once per CU, blocks drawing tiles from per-XCD tickets.  Same tiles,

@@ -52,8 +52,11 @@ def bench_attn(iters):
 
 def bench_gemm(iters):
     m_big = int(os.environ.get("BENCH_M", "25200"))          # the stage's query rows: 25200 (s1), 21600 (s2, s3)
-    for name, M, N, K, epi in (("qkv", m_big, 15360, 5120, 0), ("o", m_big, 5120, 5120, 3), ("ffn0", m_big, 13824, 5120, 1),
-                               ("ffn2", m_big, 5120, 13824, 3), ("qkv_s0", 7200, 15360, 5120, 0), ("sq8k", 8192, 8192, 8192, 0)):
+    shapes = (("qkv", m_big, 15360, 5120, 0), ("o", m_big, 5120, 5120, 3), ("ffn0", m_big, 13824, 5120, 1),
+              ("ffn2", m_big, 5120, 13824, 3), ("qkv_s0", 7200, 15360, 5120, 0), ("sq8k", 8192, 8192, 8192, 0))
+    if os.environ.get("BENCH_SHAPES"):                       # "name:M:N:K:epi,..." (e.g. the 1.3B / 480p block shapes)
+        shapes = tuple((f[0], int(f[1]), int(f[2]), int(f[3]), int(f[4])) for f in (x.split(":") for x in os.environ["BENCH_SHAPES"].split(",")))
+    for name, M, N, K, epi in shapes:
         # BENCH_PAD_K / BENCH_PAD_N: extra elements in the leading dimension of the K-contiguous operands / of C and the residual
         # (dev: does the power-of-two-ish row stride camp on a few HBM channels?)
         pk, pn = int(os.environ.get("BENCH_PAD_K", "0")), int(os.environ.get("BENCH_PAD_N", "0"))
@@ -68,18 +71,25 @@ def bench_gemm(iters):
         ctr = torch.zeros(8, dtype=torch.int32, device=dev)
         fn_t = lambda: _lib.check(lib.mmpl_gemm_tickets(_lib.ptr(A), K + pk, _lib.ptr(W), K + pk, _lib.ptr(b), _lib.ptr(Cc), N + pn, M, N, K, epi, _lib.ptr(res),
                                                         N + pn, _lib.ptr(gate), N, 3600, _lib.ptr(ctr), _lib.stream_ptr()))
-        ms, ms_t = timeit(fn, iters), timeit(fn_t, iters)
-        ms2, ms_t2 = timeit(fn, iters), timeit(fn_t, iters)
-        ms, ms_t = min(ms, ms2), min(ms_t, ms_t2)
+        nb = lib.mmpl_gemm_scratch_bytes()
+        scratch = torch.zeros(nb, dtype=torch.uint8, device=dev)
+        fn_s = lambda: _lib.check(lib.mmpl_gemm_scratch(_lib.ptr(A), K + pk, _lib.ptr(W), K + pk, _lib.ptr(b), _lib.ptr(Cc), N + pn, M, N, K, epi, _lib.ptr(res),
+                                                        N + pn, _lib.ptr(gate), N, 3600, _lib.ptr(scratch), nb, _lib.stream_ptr()))
+        ms, ms_t, ms_s = timeit(fn, iters), timeit(fn_t, iters), timeit(fn_s, iters)
+        ms2, ms_t2, ms_s2 = timeit(fn, iters), timeit(fn_t, iters), timeit(fn_s, iters)
+        ms, ms_t, ms_s = min(ms, ms2), min(ms_t, ms_t2), min(ms_s, ms_s2)
         print(f"gemm {name}: M={M} N={N} K={K} epi={epi}  {ms:8.3f} ms  {2.0 * M * N * K / ms / 1e9:8.1f} TFLOP/s   |  tile tickets {ms_t:8.3f} ms  "
-              f"{2.0 * M * N * K / ms_t / 1e9:8.1f} TFLOP/s", flush=True)
+              f"{2.0 * M * N * K / ms_t / 1e9:8.1f} TFLOP/s   |  + split-K tail {ms_s:8.3f} ms  {2.0 * M * N * K / ms_s / 1e9:8.1f} TFLOP/s", flush=True)
 
 
 def bench_gemm_ref(iters):
     """yardstick only (never on the product path): the vendor library (torch.matmul -> hipBLASLt / rocBLAS) on the same shapes
     and the same random operands, plain C = A W^T without bias / epilogue"""
-    for name, M, N, K in (("qkv", 25200, 15360, 5120), ("o", 25200, 5120, 5120), ("ffn0", 25200, 13824, 5120), ("ffn2", 25200, 5120, 13824),
-                          ("qkv_s0", 7200, 15360, 5120), ("sq8k", 8192, 8192, 8192)):
+    shapes = (("qkv", 25200, 15360, 5120), ("o", 25200, 5120, 5120), ("ffn0", 25200, 13824, 5120), ("ffn2", 25200, 5120, 13824),
+              ("qkv_s0", 7200, 15360, 5120), ("sq8k", 8192, 8192, 8192))
+    if os.environ.get("BENCH_SHAPES"):
+        shapes = tuple((f[0], int(f[1]), int(f[2]), int(f[3])) for f in (x.split(":") for x in os.environ["BENCH_SHAPES"].split(",")))
+    for name, M, N, K in shapes:
         A = torch.randn(M, K, device=dev).to(BF)
         W = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(BF)
         out = torch.empty(M, N, device=dev, dtype=BF)
