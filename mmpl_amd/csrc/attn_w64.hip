@@ -101,6 +101,12 @@ struct Ctx {
     asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], a[%c2:%c3], %4, a[%c0:%c1]" ::"i"(oa), "i"(oa + 15), "i"(va), "i"(va + 3),
                  "v"(P[X][ks]));
   }
+  // dev timing mock (-DW64_ABL=256 + W64_PVSPLIT=1 schedule; garbage results): the PV FLOPs as two 16x16x32 MFMAs per 32x32x16 one,
+  // the gap's fillers split around the second -- what would the other instruction shape buy in this loop?
+  template <int X, int G, int HALF> MMPL_DEV void mfma_pv_h() {
+    constexpr int ks = G >> 2, nb = G & 3, oa = AO + 64 * X + 16 * nb + 8 * HALF, va = AV + 4 * G;
+    asm volatile("v_mfma_f32_16x16x32_bf16 a[%c0:%c1], a[%c2:%c3], %4, a[%c0:%c1]" ::"i"(oa), "i"(oa + 3), "i"(va), "i"(va + 3), "v"(P[X][ks]));
+  }
   // ---------------------------------------------------------------- LDS fragment reads
   MMPL_DEV void addr_k() { if constexpr (W64_ABL & 4) return; asm volatile("v_add_u32 %0, %1, %2" : "=v"(kaddr) : "s"(rk), "v"(kbase)); }
   MMPL_DEV void addr_v() {
