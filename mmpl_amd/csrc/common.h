@@ -25,13 +25,14 @@ MMPL_DEV bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 MMPL_DEV float rbf(float f) { return bf2f(f2bf(f)); }  // round through bf16
 
 MMPL_DEV float gelu_tanh(float x) {
-  // torch GELU(approximate='tanh'): 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3)))
-  const float kBeta = 0.7978845608028654f, kKappa = 0.044715f;
-  float inner = kBeta * (x + kKappa * x * x * x);
-  // 0.5 * (1 + tanh(u)) == 1 / (1 + exp(-2u)).  v_rcp_f32 (1 ulp) instead of the IEEE division sequence (v_div_scale x2, v_rcp,
-  // 4 FMAs, v_div_fmas, v_div_fixup: 10 VALU instructions per value, 128 values per lane in a GEMM epilogue): the value is
-  // rounded to bf16 right after, 2^15 times coarser than the difference
-  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * inner));
+  // torch GELU(approximate='tanh'): 0.5*x*(1+tanh(u)), u = sqrt(2/pi)*(x+0.044715*x^3); 0.5*(1+tanh(u)) == 1/(1+exp(-2u)) ==
+  // 1/(1+2^a) with a = x*(c1 + c2*x^2), c1 = -2*sqrt(2/pi)*log2(e), c2 = 0.044715*c1: 3 multiplies, one FMA, one add, v_exp_f32
+  // (which IS 2^a) and v_rcp_f32 (1 ulp) instead of the IEEE division sequence (v_div_scale x2, v_rcp, 4 FMAs, v_div_fmas,
+  // v_div_fixup: 10 VALU instructions per value, 128 values per lane in a GEMM epilogue).  The value is rounded to bf16 right
+  // after, 2^15 times coarser than the difference.
+  constexpr float c1 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, c2 = 0.044715f * c1;
+  const float a = x * __builtin_fmaf(x * x, c2, c1);
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a));
 }
 MMPL_DEV float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
