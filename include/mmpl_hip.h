@@ -114,6 +114,9 @@ int mmpl_gemm_tickets(const void* A, int lda, const void* W, int ldw, const void
  * counters | pad to 2048 B | partials].  Launches sharing a scratch must be stream-ordered.  (mmpl_dit_forward keeps one in its
  * workspace.) */
 size_t mmpl_gemm_scratch_bytes(void);
+/* 1 if workgroup b of a launch runs on XCD b & 7 on the current device (checked on the hardware once per device; the split-K launch
+ * needs it and is skipped otherwise), else 0.  Synchronises on first use: not inside a stream capture. */
+int mmpl_device_xcd_round_robin(void);
 int mmpl_gemm_scratch(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N, int K,
                       int epi, const void* res, int ldres, const void* gate, int gate_frame_stride, int rows_per_frame,
                       void* scratch, size_t scratch_bytes, mmpl_stream_t stream);

@@ -505,6 +505,7 @@ int mmpl_gemm_tickets(const void* A, int lda, const void* W, int ldw, const void
 }
 
 size_t mmpl_gemm_scratch_bytes(void) { return 2048 + mmpl_gemm_splitk_ws_bytes(); }
+int mmpl_device_xcd_round_robin(void) { return mmpl_xcd_dispatch_ok(true) ? 1 : 0; }
 
 int mmpl_gemm_scratch(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N, int K,
                       int epi, const void* res, int ldres, const void* gate, int gate_frame_stride, int rows_per_frame,

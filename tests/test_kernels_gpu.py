@@ -105,8 +105,10 @@ def test_gemm_split_k_tail(lib, M, N, K, epi, split):
     out = outs[0]
     assert torch.isfinite(out.float()).all()
     tiles_differ = (out != plain).reshape(-1)[: (M // 256) * 256 * N].reshape(M // 256, 256, N // 256, 256).any(dim=3).any(dim=1)
-    if split:
+    if split and lib.mmpl_device_xcd_round_robin():            # (no split on a device whose dispatch order the probe did not confirm)
         assert 0 < int(tiles_differ.sum()) <= 128
+    elif split:
+        assert int(tiles_differ.sum()) <= 128
     else:
         assert torch.equal(out, plain)
     y = A.float() @ W.float().t() + b.float()
