@@ -53,6 +53,14 @@ def test_kernel_entry_points_reject_bad_shapes():
     assert _err(lib.mmpl_attn_fwd(None, 128, None, 128, kp, kp, 128, 128, 25, 64, 64, 1, 0.088, None))     # > 24 pages
     assert _err(lib.mmpl_attn_fwd_variant(None, 128, None, 128, kp, kp, 128, 128, 1, 64, 64, 1, 0.088, None, 0, 9, 0, None))   # unknown kernel variant
     assert _err(lib.mmpl_attn_fwd_variant(None, 128, None, 128, kp, kp, 128, 128, 1, 64, 64, 1, 0.088, None, 0, 2, 0, None))   # the removed ping-pong kernel
+    # mmpl_gemm_scratch: the scratch must be there, large enough and 256-byte aligned (checked before anything touches it)
+    nb = lib.mmpl_gemm_scratch_bytes()
+    assert nb > 2048
+    args = (None, 128, None, 128, None, None, 128, 1024, 256, 128, 0, None, 0, None, 0, 1)
+    assert "scratch missing" in _err(lib.mmpl_gemm_scratch(*args, None, nb, None))
+    assert "scratch missing" in _err(lib.mmpl_gemm_scratch(*args, C.c_void_p(0x10000), nb - 1, None))
+    assert "256-byte aligned" in _err(lib.mmpl_gemm_scratch(*args, C.c_void_p(0x10010), nb, None))
+    assert "unknown epilogue" in _err(lib.mmpl_gemm_scratch(*(args[:10] + (99,) + args[11:]), C.c_void_p(0x10000), nb, None))
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="asserts the no-GPU failure mode")
