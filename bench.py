@@ -80,6 +80,16 @@ def parse():
                          "(the reference's device_cond/device_uncond seam) instead of N chunk lanes; default from 4 ranks on")
     ap.add_argument("--no-cfg-split", action="store_true", help="N chunk lanes whatever N is")
     ap.add_argument("--eager", action="store_true", help="time plain launches instead of one hipGraph replay per step")
+    ap.add_argument("--wavefront-chunks", type=int, default=0,
+                    help="C > 0: instead of K rotating steps, run ONE video of C chunks through the real pipeline and the real dependency chain "
+                         "(chunk c on lane c %% lanes, RCCL anchor hand-off after the anchor stage, VAE consumer transform) and report the MEASURED "
+                         "wall clock first noise -> last latent: value = 21 C / wall (SURVEY 8d), per-rank busy fraction, stagger, hand-off latency")
+    ap.add_argument("--sampling-steps", type=int, default=50, help="UniPC steps per stage of --wavefront-chunks (50 = the reference's; fewer = a "
+                         "shorter functional run whose value is NOT the metric and is labelled so)")
+    ap.add_argument("--heavy-tail", action="store_true",
+                    help="NOT the headline: the statistics real checkpoints have and unit-variance synthetic weights do not (QK-norm gains x8, "
+                         "six massive-activation channels -- the weights of tests/test_fullsize_gpu.py's heavy-tail case): how much of the "
+                         "self-attention kernel's speed is its max-free FAST pass?  Reports attn_blocks_redone_fraction next to the attention ms")
     ap.add_argument("--cpu-budget-s", type=float, default=150.0, help="stop adding stage shapes to the CPU baseline after this many seconds")
     return ap.parse_args()
 
@@ -168,6 +178,156 @@ def dry_run_launch(world: int, rank: int):
     dist.destroy_process_group()
 
 
+def run_wavefront(args, dist, rank, world, dev, gloo):
+    """`--wavefront-chunks C`: one video of C chunks, measured.  The real pipeline (mmpl_amd.pipeline: stage loop, hipGraph per
+    denoise step, hand-off sink after the anchor stage), the real dependency chain (run_chunk_wavefront: chunk c on lane c % lanes
+    waits for chunk c-1's anchors, turns them into its two initial latents with the VAE prefix decode / encode) and the real
+    exchange (ChunkHandoff: RCCL p2p on a side stream behind the host-side ready handshake; 2-rank CFG pairs from 4 ranks on).
+    Reference: Wan_fps_inference_parallel_4gpu_20s.py:180-261 (threads + .pt files + 1 Hz poll), ..._5-60s.py:188-381."""
+    import types
+    from mmpl_amd.geometry import RESOLUTIONS, Geometry
+    from mmpl_amd.handoff import CfgPair, ChunkHandoff, handoff_to_initial_latent, run_chunk_wavefront
+    from mmpl_amd.pipeline import CausalFPSInferencePipeline
+    from mmpl_amd.stage_plan import T2V_STAGE_SHAPES, dit_forward_flops
+    from mmpl_amd.synthetic import WAN_CONFIGS, dit_state_dict, vae_state_dict
+    from mmpl_amd.wan_wrapper import SyntheticTextEncoder, WanFPSWrapper, WanVAEWrapper
+    torch.set_grad_enabled(False)
+    C_ = args.wavefront_chunks
+    cfg = WAN_CONFIGS[args.model]
+    lat_h, lat_w = (16, 24) if args.res == "tiny" else RESOLUTIONS[args.res]
+    geo = Geometry(lat_h, lat_w)
+    cfg_split = args.cfg_split or (not args.no_cfg_split and world >= 4 and world % 2 == 0)
+    pair, heads, lay = (None, None, None)
+    if world > 1 and cfg_split:
+        pair, heads, lay = CfgPair.build(world, dev, True)
+    n_lanes = world // 2 if pair is not None else world
+    lane = lay["lane_of"][rank] if lay else rank
+    gen = WanFPSWrapper("Wan2.1-T2V-14B", timestep_shift=5.0, is_causal=True, model_config=cfg, geometry=geo, device=str(dev))
+    gen.load_state_dict(dit_state_dict(cfg, seed=1234, device=dev))
+    enc = SyntheticTextEncoder(cfg.get("text_dim", 4096), str(dev))
+    vae = WanVAEWrapper(geometry=geo, device=str(dev), state_dict=vae_state_dict(seed=7))
+    pargs = types.SimpleNamespace(model_kwargs={}, num_train_timestep=1000, timestep_shift=5.0, guidance_scale=5.0, negative_prompt="",
+                                  independent_first_frame=False, sampling_steps=args.sampling_steps)
+    pipe = CausalFPSInferencePipeline(pargs, str(dev), generator=gen, text_encoder=enc, vae=vae, save=None, mode="t2v", geometry=geo)
+    pipe.cfg_pair = pair
+    ho = None
+    if world == 1:
+        ho = None
+    elif pair is None or pair.role == 0:
+        ho = ChunkHandoff((1, 8, 16, lat_h, lat_w), dev, group=heads)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    noises = [torch.randn([1, 21, 16, lat_h, lat_w], generator=g).to(torch.bfloat16) for _ in range(C_)]
+    # untimed warm-up: one 1-step chunk and the consumer transform compile / allocate everything (graphs are re-captured per stage)
+    pipe.sampling_steps = 1
+    _, lat = pipe.inference(noises[0].to(dev), ["warm-up"], return_latents=True, decode=False)
+    handoff_to_initial_latent(vae, torch.cat([lat[:, :1], lat[:, [2, 3, 10, 11, 12, 19, 20]]], dim=1))
+    pipe.sampling_steps = args.sampling_steps
+    torch.cuda.synchronize()
+    marks = {}
+
+    def make_chunk(c, initial, sink):
+        m = marks.setdefault(c, {})
+        m["t_start"] = time.time()
+
+        def tee(t):
+            torch.cuda.synchronize()                   # the anchor stage is really done (the host would otherwise be ahead of the GPU)
+            m["t_anchor"] = time.time()
+            sink(t)
+        pipe.handoff_sink = tee
+        pipe.handoff_poll = ho.poll if ho is not None else None
+        _, lat_c = pipe.inference(noises[c].to(dev), ["a cat running on the grass"], initial_latent=initial, return_latents=True, decode=False)
+        torch.cuda.synchronize()
+        m["t_end"] = time.time()
+        return lat_c
+
+    def to_initial(recv):
+        return handoff_to_initial_latent(vae, recv.to(dev))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.time()
+    if world == 1:
+        initial = None
+        for c in range(C_):                              # one rank: the chain is sequential (chunk c+1 needs chunk c's anchors)
+            got = {}
+            lat_c = make_chunk(c, initial, lambda t: got.setdefault("h", t))
+            if c + 1 < C_:
+                initial = to_initial(got["h"])
+    else:
+        run_chunk_wavefront(make_chunk, C_, ho, to_initial, gather=False, pair=pair, lane=lane, n_lanes=n_lanes,
+                            initial_like=torch.empty([1, 2, 16, lat_h, lat_w], device=dev, dtype=torch.bfloat16))
+    barrier()
+    wall = time.time() - t0
+    mine = {"rank": rank, "marks": marks, "handoff": (ho.stats if ho is not None else {}), "t0": t0}
+    everyone = [mine]
+    if dist is not None and world > 1:
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+    if rank != 0:
+        return
+    S = (lat_h // 2) * (lat_w // 2)
+    stage_flops = [dit_forward_flops(cfg, S, q, kv) for q, kv in T2V_STAGE_SHAPES]
+    chunks = {}
+    for e in everyone:
+        if lay is not None and lay["role_of"][e["rank"]] != 0:
+            continue
+        for c, m in e["marks"].items():
+            chunks[c] = dict(m, rank=e["rank"])
+    ho_stats = {}
+    for e in everyone:
+        for c, st in e["handoff"].items():
+            ho_stats.setdefault(c, {}).update(st)
+    order = sorted(chunks)
+    dur = [chunks[c]["t_end"] - chunks[c]["t_start"] for c in order]
+    anchor = [chunks[c].get("t_anchor", chunks[c]["t_end"]) - chunks[c]["t_start"] for c in order]
+    stagger = [chunks[order[i + 1]]["t_start"] - chunks[order[i]]["t_start"] for i in range(len(order) - 1)]
+    busy = {}
+    for c in order:
+        busy[chunks[c]["rank"]] = busy.get(chunks[c]["rank"], 0.0) + chunks[c]["t_end"] - chunks[c]["t_start"]
+    lat_ho = {c: st["t_recv_done"] - max(st.get("t_sink", 0.0), st.get("t_ready", 0.0)) for c, st in ho_stats.items() if "t_recv_done" in st}
+    wait_ho = {c: max(0.0, st["t_sink"] - st["t_ready"]) for c, st in ho_stats.items() if "t_sink" in st and "t_ready" in st}
+    value = 21.0 * C_ / wall
+    # the occupancy model of the default N > 1 line, fed by THIS run's chunk / anchor times (kept for comparison)
+    later = dur[1:] if len(dur) > 1 else dur
+    later_anchor = anchor[1:] if len(anchor) > 1 else anchor
+    d_mean, a_mean = sum(later) / len(later), sum(later_anchor) / len(later_anchor)
+    modelled = min(float(n_lanes), d_mean / a_mean) * 21.0 / d_mean
+    fwd_per_chunk = [(args.sampling_steps * 2 + 2) for _ in range(4)]
+    flops = sum(f * n for f, n in zip(stage_flops, fwd_per_chunk)) * C_          # (chunks >= 2 skip s0's denoising: upper bound)
+    full = args.sampling_steps == 50
+    res = {"metric": "video_latent_frames_per_sec", "value": value, "unit": "latent-frames/s",
+           "n_gpus": dist.get_world_size() if dist is not None else 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           **({"functional_only": "gloo backend: ranks share GPUs, exchanges staged through the host -- exercises the N > 1 code paths, "
+                                  "not a scaling measurement"} if gloo else {}),
+           **({} if full else {"not_the_metric": f"{args.sampling_steps} sampling steps per stage instead of the reference's 50: a functional / "
+                                                 "timing-structure run; `value` is the rate of THIS shortened video"}),
+           "config": {"workload": f"Wan2.1-T2V-{args.model} {args.res}: ONE video of {C_} chunks (21 latent frames each) through the real pipeline, "
+                                  f"{args.sampling_steps} UniPC steps x CFG per stage, anchors handed lane -> lane + 1",
+                      "frame_seqlen": S, "latent_hw": [lat_h, lat_w], "sampling_steps": args.sampling_steps, "guidance_scale": 5.0,
+                      "timed_path": "wall clock first noise -> last latent over all ranks (barrier + synchronize on both sides)",
+                      "parallelism": f"measured wavefront: {C_} chunks on {n_lanes} lane(s)" +
+                                     (" x 2 (cond|uncond) CFG split" if pair is not None else "") +
+                                     (", RCCL p2p anchor hand-off behind a host-side ready handshake" if world > 1 and not gloo else
+                                      (", hand-off staged through the host (gloo)" if world > 1 else ", sequential chain on one rank"))},
+           "wall_s": wall, "chunks": C_, "lanes": n_lanes,
+           "value_modelled": modelled,
+           "value_modelled_note": "min(lanes, chunk_s / anchor_s) * 21 / chunk_s with this run's mean chunk and anchor-stage times of chunks >= 2 "
+                                  "(the occupancy model the K-steps N > 1 line prints)",
+           "chunk_s": dur, "anchor_done_after_s": anchor, "stagger_s": stagger,
+           "rank_busy_fraction": {str(r): b / wall for r, b in sorted(busy.items())},
+           "handoff_latency_s": {str(c): v for c, v in sorted(lat_ho.items())},
+           "handoff_latency_note": "recv complete - max(anchors available on the producer, consumer ready): RCCL p2p + header (+ host staging under gloo)",
+           "producer_waited_for_consumer_s": {str(c): v for c, v in sorted(wait_ho.items())},
+           "achieved_pflops_all_gpus_upper_bound": flops / wall / 1e15}
+    print(json.dumps(res), flush=True)
+
+
 def main():
     args = parse()
     in_launch = "RANK" in os.environ
@@ -197,6 +357,12 @@ def main():
     gloo = dist is not None and args.dist_backend == "gloo"
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
+    if args.wavefront_chunks > 0:
+        run_wavefront(args, dist, rank, world, dev, gloo)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     pair, lanes, lane, n_lanes = None, None, rank, world
     if not args.cfg_split and not args.no_cfg_split and world >= 4 and world % 2 == 0:
         args.cfg_split = True            # more chunk lanes than the wavefront can keep busy: spend the ranks on the CFG pair instead
@@ -224,7 +390,18 @@ def main():
         eng.set_image_kv(*eng.precompute_image_context(torch.randn(257, 1280, device=dev).to(torch.bfloat16)))
     else:
         eng = DitEngine(cfg, lat_h, lat_w, dev)
-        eng.load_state_dict(dit_state_dict(cfg, seed=1234, device=dev))
+        sd = dit_state_dict(cfg, seed=1234, device=dev)
+        if args.heavy_tail:
+            for l in range(cfg["num_layers"]):
+                for k in ("self_attn.norm_q.weight", "self_attn.norm_k.weight"):
+                    sd[f"blocks.{l}.{k}"] = (sd[f"blocks.{l}.{k}"].float() * 8.0).to(torch.bfloat16)
+            b = sd["patch_embedding.bias"].float()
+            cols = [c % cfg["dim"] for c in (7, 300, 1111, 2049, 3333, 5000)]
+            b[cols] = torch.tensor([60.0, -60.0, 45.0, -45.0, 60.0, -50.0], device=b.device)
+            sd["patch_embedding.bias"] = b.to(torch.bfloat16)
+        eng.load_state_dict(sd)
+        del sd
+    attn_stats = eng.enable_attn_stats()      # {query blocks, blocks the FAST softmax pass could not hold}: one atomic per block
     S = eng.S
     plan = StagePlan(args.mode)
     stage_shapes = T2V_STAGE_SHAPES if args.mode == "t2v" else I2V_STAGE_SHAPES
@@ -377,6 +554,8 @@ def main():
     # the K timed steps keep rotating through the four stage shapes; every step is also bracketed by a HIP event pair so
     # that the chunk time can be assembled per stage (exact for any K, not only multiples of 4)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    attn_stats.zero_()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev[i][0].record()
@@ -386,6 +565,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     step_s = [e0.elapsed_time(e1) * 1e-3 for e0, e1 in ev]
+    attn_blocks, attn_redone = eng.read_attn_stats()        # of the timed region (graph replays included)
     # ---- eager pass (after the timed region when that one replayed graphs): one rotation of the four stages with a hipEvent
     # pair around every self-attention launch (all kernel classes with --profile-all) -> `eager` figures and `roofline`
     eager_step_s = None
@@ -477,6 +657,12 @@ def main():
             "achieved_pflops_per_gpu": achieved_pf,
             "mfma_frac_whole_step": achieved_pf * 1e3 / MFMA_PEAK_TFLOPS,
             "vae_decode_s_per_chunk": vae_s,
+            # data dependence of the self-attention kernel IN THE TIMED REGION: 256-row query blocks whose max-free FAST softmax pass
+            # overflowed / underflowed and were redone by the GENERAL pass (attn_w64.hip); caches hold K / V written by real forwards
+            "attn_blocks": attn_blocks, "attn_blocks_redone": attn_redone,
+            "attn_blocks_redone_fraction": (attn_redone / attn_blocks) if attn_blocks else None,
+            **({"weights": "heavy-tailed synthetic (QK-norm gains x8, six massive-activation channels): NOT the headline workload"}
+               if args.heavy_tail else {}),
         }
         if eager_step_s is not None:
             e_stage, e_chunk = assemble_chunk_seconds(eager_step_s, 0, stage_flops)
@@ -487,27 +673,23 @@ def main():
             a = prof["attn_self"]
             ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
             traffic, traffic_src = None, None
-            if args.model == "14B" and args.res == "720p" and args.mode == "t2v":
-                # HBM bytes per launch cannot be collected inside this process (rocprofv3 --pmc wraps the program): the newest
-                # committed PMC passes.  r03+: collected on THIS command (tools/r03_profiles.sh: bench.py under rocprofv3 --pmc
-                # FETCH_SIZE / WRITE_SIZE in separate passes), mean over the rotation's self-attention ops.
-                import glob
-                cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]*_pmc_attention_hbm.json")))
-                if cands:
-                    traffic = json.load(open(cands[-1]))["mean_hbm_bytes_per_op"]
-                    traffic_src = (f"profiles/{os.path.basename(cands[-1])} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py itself, "
-                                   "mean of the rotation's self-attention ops)")
-                else:
-                    pmc = os.path.join(ROOT, "profiles", "r02_pmc_attention_hbm.json")
-                    if os.path.exists(pmc):
-                        st = json.load(open(pmc))["stages"]
-                        traffic = sum(st[k]["hbm_bytes"] for k in ("s0", "s1", "s2", "s3")) / 4.0
-                        traffic_src = "profiles/r02_pmc_attention_hbm.json (round-2 kernel, one-op helper, mean of s0..s3)"
+            if args.model == "14B" and args.res == "720p" and args.mode == "t2v" and not args.heavy_tail:
+                # Fabric bytes per op cannot be collected inside this process (rocprofv3 --pmc wraps the program): the committed PMC
+                # passes over THIS command (tools/r04_profiles.sh: bench.py under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+                # passes, mean over the rotation's self-attention ops).  The file is named explicitly by profiles/PMC_TRAFFIC.json,
+                # written by the collection script -- not picked by a sorted glob.
+                idx = os.path.join(ROOT, "profiles", "PMC_TRAFFIC.json")
+                if os.path.exists(idx):
+                    name = json.load(open(idx))["attention_traffic_file"]
+                    traffic = json.load(open(os.path.join(ROOT, "profiles", name)))["mean_hbm_bytes_per_op"]
+                    traffic_src = (f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py itself, "
+                                   "mean of the rotation's self-attention ops; a PREVIOUSLY collected figure, not a measurement of this run)")
             res["roofline"] = {"bound": "mfma", "kernel": "attn_w64_kernel (self-attention over the KV-slot page table; one op = main launch + split-KV tail launch + merge)",
                                "measured_in": ("eager pass right after the timed graph replays (hipEvent pair per launch on the launch stream)"
                                                if graphed else "timed region (hipEvent pair per launch on the launch stream)"),
                                "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-                               "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+                               "traffic": traffic, "traffic_unit": "fabric bytes per op (L2 <-> memory side; Infinity-Cache hits are counted, so this is an upper bound of HBM bytes)",
+                               "traffic_source": traffic_src,
                                "avg_launch_ms": a["ms"] / a["launches"], "launches": a["launches"],
                                "algorithmic_flops_per_launch": a["flops"] / a["launches"]}
             # share of the timed wall clock spent in the roofline kernel (per rank; exact, unlike a share of timed kernels)

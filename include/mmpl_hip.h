@@ -57,6 +57,12 @@ int mmpl_dit_precompute_context(MmplDit* h, const void* context, void* cross_k, 
  * NULL, NULL restores the text-only cross-attention. */
 int mmpl_dit_set_image_kv(MmplDit* h, const void* img_k, const void* img_v, int n_img_tokens);
 
+/* Optional diagnostics of the self-attention kernel's data dependence.  attn_w64_kernel runs a max-free FAST softmax pass per
+ * 256-row query block and redoes the block with the GENERAL (running-reference) pass if any row sum left [2^-40, 2^100].
+ * stats_dev: 2 x uint64 in device memory (borrowed; zero them yourself), incremented by every self-attention launch of
+ * mmpl_dit_forward on this handle, inside hipGraph replays too: [0] += blocks run, [1] += blocks redone.  NULL switches it off. */
+int mmpl_dit_set_attn_stats(MmplDit* h, void* stats_dev);
+
 /* CausalFPSWanModel._forward_inference (causal_fps_model.py:708-837) behind WanFPSWrapper.forward
  * (utils/wan_wrapper.py:422-493).
  *   x_in / out : dev [n_frames, in_dim, lat_h, lat_w] / [n_frames, 16, lat_h, lat_w]  (the pipeline's [B=1, F, C, H, W] layout)
@@ -114,8 +120,9 @@ int mmpl_gemm_tickets(const void* A, int lda, const void* W, int ldw, const void
  * counters | pad to 2048 B | partials].  Launches sharing a scratch must be stream-ordered.  (mmpl_dit_forward keeps one in its
  * workspace.) */
 size_t mmpl_gemm_scratch_bytes(void);
-/* 1 if workgroup b of a launch runs on XCD b & 7 on the current device (checked on the hardware once per device; the split-K launch
- * needs it and is skipped otherwise), else 0.  Synchronises on first use: not inside a stream capture. */
+/* Diagnostic: 1 if workgroup b of a launch runs on XCD b & 7 on the current device (checked on the hardware once per device), else
+ * 0.  The tile / head orders use that mapping for L2 locality only; since round 4 no kernel depends on it for correctness (the
+ * split-K launch exchanges its partials with system-scope accesses).  Synchronises on first use: not inside a stream capture. */
 int mmpl_device_xcd_round_robin(void);
 int mmpl_gemm_scratch(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N, int K,
                       int epi, const void* res, int ldres, const void* gate, int gate_frame_stride, int rows_per_frame,
@@ -151,8 +158,14 @@ int mmpl_cfg_unipc_step_table(const void* flow_cond, const void* flow_uncond, vo
                               const float* timestep_table_dev, int n_timestep, int n_steps, mmpl_stream_t stream);
 
 /* ---- Wan 3D causal VAE (wan/modules/vae.py:483-569 behind WanVAEWrapper, utils/wan_wrapper.py:54-113) ----
- * Weights: mmpl_vae_num_weights() dev pointers in the reference state_dict order (mmpl_vae_weight_name(i)); conv weights
- * repacked host-side to [Cout, taps * Cin] (Cin contiguous; Cin 3/16 zero-padded to 32, decoder.head Cout 3 -> 4).
+ * Weights: mmpl_vae_num_weights() dev pointers in the order of mmpl_vae_weight_name(i): the reference's state_dict keys, conv
+ * weights repacked host-side to [Cout, taps * Cin] (tap-major, Cin contiguous; Cin 3/16 zero-padded to 32, decoder.head Cout
+ * 3 -> 4).  Every 3x3(x3) stride-1 conv is listed TWICE: "<conv>.weight" as above and a synthetic entry "<conv>.weight.frag" =
+ * the same [Cout, taps * Cin] matrix in the fragment-major packing conv_halo_kernel loads (Cout zero-padded to a multiple of 16):
+ * element (n, tap, c) at ((((c / 32) * taps + tap) * (Cout_pad / 16) + n / 16) * 4 + (c % 32) / 8) * 16 + n % 16) * 8 + c % 8,
+ * i.e. per (32-channel chunk, tap, 16-row group) the 64 lanes' 16 bytes back to back, lane = 16 * (8-channel k chunk) + row
+ * (mmpl_amd/vae.py VaeEngine._frag_pack is the reference packer).  bind_weights rejects any other count: a caller that binds
+ * by state-dict name must produce the .frag entries too.
  * mode 0 = decode, 1 = encode.  mean / inv_std: host float[16] (bf16-rounded values of the wrapper's scale tensors). */
 typedef struct MmplVae MmplVae;
 int mmpl_vae_num_weights(void);

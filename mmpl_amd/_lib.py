@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmmpl_hip.so")
 # every symbol include/mmpl_hip.h declares (tests/test_abi.py checks this list against the header and the .so)
 SYMBOLS = [
     "mmpl_dit_num_weights", "mmpl_dit_weight_name", "mmpl_dit_create", "mmpl_dit_destroy", "mmpl_dit_bind_weights",
-    "mmpl_dit_workspace_bytes", "mmpl_dit_context_workspace_bytes", "mmpl_dit_precompute_context", "mmpl_dit_forward", "mmpl_dit_set_image_kv", "mmpl_clip_visual", "mmpl_clip_visual_workspace_bytes",
+    "mmpl_dit_workspace_bytes", "mmpl_dit_context_workspace_bytes", "mmpl_dit_precompute_context", "mmpl_dit_forward", "mmpl_dit_set_attn_stats", "mmpl_dit_set_image_kv", "mmpl_clip_visual", "mmpl_clip_visual_workspace_bytes",
     "mmpl_attn_fwd", "mmpl_attn_fwd_ws", "mmpl_attn_fwd_variant", "mmpl_attn_workspace_bytes", "mmpl_gemm", "mmpl_gemm_tickets", "mmpl_gemm_scratch", "mmpl_gemm_scratch_bytes", "mmpl_device_xcd_round_robin", "mmpl_layernorm", "mmpl_qknorm_rope", "mmpl_cfg_unipc_step", "mmpl_cfg_unipc_step_table",
     "mmpl_vae_num_weights", "mmpl_vae_weight_name", "mmpl_vae_create", "mmpl_vae_destroy", "mmpl_vae_bind_weights",
     "mmpl_vae_workspace_bytes", "mmpl_vae_decode", "mmpl_vae_encode",
@@ -101,6 +101,7 @@ def load() -> C.CDLL:
     lib.mmpl_i2v_img_proj_workspace_bytes.argtypes = [ci, ci, ci]
     lib.mmpl_i2v_img_proj_workspace_bytes.restype = sz
     lib.mmpl_dit_set_image_kv.argtypes = [vp, vp, vp, ci]
+    lib.mmpl_dit_set_attn_stats.argtypes = [vp, vp]
     lib.mmpl_clip_visual_workspace_bytes.argtypes = [ci, ci, ci, ci]
     lib.mmpl_clip_visual_workspace_bytes.restype = sz
     lib.mmpl_clip_visual.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, C.POINTER(vp), C.POINTER(vp), cf, vp, vp, sz, vp]

@@ -132,8 +132,11 @@ def main(argv=None):
         """the Wan-I2V model type's conditioning for a chunk whose first pixel frame is `frame` ([3, H, W] in [-1, 1])"""
         if clip is None:
             return None
-        if frame is None:                    # the uncond rank of a CFG pair: the pipeline overwrites it with the cond rank's broadcast
-            frame = torch.zeros(3, *geo.pixel_hw, device=dev, dtype=torch.bfloat16)
+        if frame is None:
+            # the uncond rank of a CFG pair has no frame: pipeline.inference overwrites both tensors with the cond rank's broadcast,
+            # so only the shapes matter -- no CLIP tower, no 81-frame VAE encode of a zero clip on the rank that paces the pair
+            return {"clip_fea": torch.empty(257, 1280, device=dev, dtype=torch.bfloat16),
+                    "y": torch.empty(20, args.num_output_frames, geo.lat_h, geo.lat_w, device=dev, dtype=torch.bfloat16)}
         from .i2v_condition import build_image_condition
         return build_image_condition(pipe.vae, clip, frame, args.num_output_frames)
     if args.checkpoint_path:
@@ -182,6 +185,7 @@ def main(argv=None):
 
             def make_chunk(c, initial, sink):
                 pipe.handoff_sink = sink
+                pipe.handoff_poll = ho.poll if ho is not None else None
                 if c == 0:
                     initial = image_latent
                 video, _ = pipe.inference(noises[c].to(dev), [prompt], initial_latent=initial, return_latents=True,

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/mmpl_hip.h"
@@ -101,6 +102,12 @@ struct MmplDit {
   float* cos_tab = nullptr;  // [1024][64]
   float* sin_tab = nullptr;
   std::vector<const bf16_t*> w;
+  // text contexts whose zero-padded tail is ONE repeated row after the text embedding (utils/wan_wrapper.py:46-47 zeroes the
+  // padding, causal_fps_model.py:780 does not mask it): cross_k buffer -> number of distinct leading rows n; rows n .. text_len-1
+  // of that context's K (and V) are identical, so the cross-attention attends over n + 1 keys, the last one weighted
+  // text_len - n times (mmpl_dit_precompute_context fills this, mmpl_dit_forward looks its cross_k argument up)
+  std::vector<std::pair<const void*, int>> ctx_distinct;
+  unsigned long long* attn_stats = nullptr;    // mmpl_dit_set_attn_stats: {blocks, blocks redone} of the self-attention launches
   const bf16_t* G(int i) const { return w[i]; }
   const bf16_t* Lw(int l, int i) const { return w[NG + l * NL + i]; }
 };
@@ -143,7 +150,6 @@ int mmpl_dit_create(const MmplDitConfig* cfg, MmplDit** out) {
     return fail("mmpl_dit_create", "unsupported dims");
   if (cfg->lat_h % 2 || cfg->lat_w % 2 || cfg->max_frames < 1 || cfg->max_frames > 8 || (cfg->in_dim != 16 && cfg->in_dim != 36) || cfg->out_dim != 16)
     return fail("mmpl_dit_create", "unsupported geometry");
-  mmpl_xcd_dispatch_ok(true);          // once per device, here because forwards may run inside a stream capture (device_state.hip)
   MmplDit* h = new MmplDit();
   h->cfg = *cfg;
   h->gh = cfg->lat_h / 2;
@@ -206,6 +212,7 @@ struct Carver {
     return p;
   }
 };
+constexpr int kTicketInts = 64 + 256;     // 8 per-XCD tile tickets (padded to 64 ints) + 256 split-K tile counters: what a forward zeroes
 struct FwdWs {
   bf16_t *x, *xn, *big, *attn, *ksc, *vsc, *patch, *sinu, *t1, *e, *se, *e0, *emod, *emod_head, *yh;
   int* tile_counter;     // 8 ints: the per-XCD tile tickets of the large GEMMs (GemmArgs.tile_counter), zeroed at the start of a forward;
@@ -219,7 +226,9 @@ FwdWs carve_fwd(const MmplDit* h, int nF, void* base) {
   const size_t bigw = (size_t)(3 * c.dim > c.ffn_dim ? 3 * c.dim : c.ffn_dim);
   Carver k(base);
   FwdWs w;
-  w.tile_counter = (int*)k.take(64 + 512);     // first: the same place for every stage shape, so no other shape's activations ever land on it
+  // first: the same place for every stage shape, so no other shape's activations ever land on it.  take() counts bf16 elements
+  static_assert(kTicketInts * sizeof(int) % sizeof(bf16_t) == 0, "ticket area");
+  w.tile_counter = (int*)k.take(kTicketInts * sizeof(int) / sizeof(bf16_t));
   w.x = k.take(Lq * d);
   w.xn = k.take(Lq * d);
   w.big = k.take(Lq * bigw);
@@ -259,7 +268,7 @@ extern "C" {
 
 size_t mmpl_dit_workspace_bytes(const MmplDit* h, int n_frames) { return carve_fwd(h, n_frames, nullptr).bytes; }
 size_t mmpl_dit_context_workspace_bytes(const MmplDit* h) {
-  return 2 * (((size_t)h->cfg.text_len * h->cfg.dim * 2 + 255) & ~(size_t)255);
+  return 2 * (((size_t)h->cfg.text_len * h->cfg.dim * 2 + 255) & ~(size_t)255) + (((size_t)h->cfg.text_len * sizeof(int) + 255) & ~(size_t)255);
 }
 
 int mmpl_dit_precompute_context(MmplDit* h, const void* context, void* cross_k, void* cross_v, void* workspace,
@@ -275,6 +284,31 @@ int mmpl_dit_precompute_context(MmplDit* h, const void* context, void* cross_k, 
   TRY(gemm((const bf16_t*)context, c.text_dim, h->G(G_TXT0_W), c.text_dim, h->G(G_TXT0_B), t0, d, T, d, c.text_dim,
            EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 1, s));
   TRY(gemm(t0, d, h->G(G_TXT2_W), d, h->G(G_TXT2_B), ctx, d, T, d, d, EPI_BIAS, nullptr, 0, nullptr, 0, 1, s));
+  // How many leading rows of the embedded context are distinct from its last row?  The reference zeroes the padded rows of the
+  // T5 output (utils/wan_wrapper.py:46-47) and attends over all text_len of them unmasked (causal_fps_model.py:780, model.py:189):
+  // after the text embedding the T - n padded rows are ONE repeated row, so are their K and V rows in every block, and
+  // softmax over {k_0..k_{n-1}, (T - n) x k_pad} == softmax over {k_0..k_{n-1}, k_pad + ln(T - n)}: the forward attends over n + 1
+  // keys (the bench's 64-token prompt: 2 KV tiles instead of 8).  Checked on the device per prompt (bitwise row compare of what
+  // the K / V projections read); one 2 KiB read-back -- not inside a stream capture, where nothing is collapsed.
+  {
+    for (size_t i = 0; i < h->ctx_distinct.size(); ++i)
+      if (h->ctx_distinct[i].first == cross_k) { h->ctx_distinct.erase(h->ctx_distinct.begin() + i); break; }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cs);
+    if (cs == hipStreamCaptureStatusNone && !mmpl_config().cross_no_collapse && T >= 2) {
+      int* flags = (int*)k.take(((size_t)T * sizeof(int) + 1) / sizeof(bf16_t));
+      std::vector<int> hf(T);
+      HIP_TRY(mmpl_launch_rows_equal_last(ctx, d, T, d, flags, s), "rows_equal_last");
+      HIP_TRY(hipMemcpyAsync(hf.data(), flags, (size_t)T * sizeof(int), hipMemcpyDeviceToHost, s), "context flags");
+      HIP_TRY(hipStreamSynchronize(s), "context flags");
+      int n = T - 1;
+      while (n > 0 && hf[n - 1]) --n;                      // rows n .. T-1 are identical
+      if (T - n >= 2) {
+        if (h->ctx_distinct.size() >= 16) h->ctx_distinct.erase(h->ctx_distinct.begin());
+        h->ctx_distinct.push_back({cross_k, n});
+      }
+    }
+  }
   for (int l = 0; l < c.num_layers; ++l) {
     bf16_t* kl = (bf16_t*)cross_k + (size_t)l * T * d;
     bf16_t* vl = (bf16_t*)cross_v + (size_t)l * T * d;
@@ -292,6 +326,13 @@ int mmpl_dit_set_image_kv(MmplDit* h, const void* img_k, const void* img_v, int 
   h->img_k = (const bf16_t*)img_k;
   h->img_v = (const bf16_t*)img_v;
   h->n_img = img_k ? n_img_tokens : 0;
+  return 0;
+}
+
+int mmpl_dit_set_attn_stats(MmplDit* h, void* stats_dev) {
+  if (!h) return fail("mmpl_dit_set_attn_stats", "null handle");
+  if (reinterpret_cast<uintptr_t>(stats_dev) % 8) return fail("mmpl_dit_set_attn_stats", "stats must be 8-byte aligned");
+  h->attn_stats = (unsigned long long*)stats_dev;
   return 0;
 }
 
@@ -318,7 +359,7 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
   hipStream_t s = (hipStream_t)stream;
   const int S = h->S, d = c.dim, f = c.ffn_dim, Lq = nF * S, H = c.num_heads, T = c.text_len;
 
-  HIP_TRY(mmpl_launch_zero_ints(w.tile_counter, 64 + 256, s), "tile counter");                  // left zero by every GEMM that uses it
+  HIP_TRY(mmpl_launch_zero_ints(w.tile_counter, kTicketInts, s), "tile counter");                  // left zero by every GEMM that uses it
   int* const tc = w.tile_counter;
   // ---- embeddings (causal_fps_model.py:757-776)
   HIP_TRY(mmpl_launch_patchify((const bf16_t*)x_in, w.patch, h->pe_k, nF, c.in_dim, c.lat_h, c.lat_w, s), "patchify");
@@ -339,6 +380,9 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
   const bool cross_w64_env = mmpl_config().cross_w64;
   const bool cross_w64 = cross_w64_env && prescale_q;       // text / image cross-attention on the 64-rows-per-wave kernel too
   const size_t layer_stride = (size_t)n_slots * S * d;
+  int ctx_n = -1;                                           // distinct leading rows of this text context, -1 = not known to collapse
+  for (const auto& e : h->ctx_distinct)
+    if (e.first == cross_k) ctx_n = e.second;
   for (int l = 0; l < c.num_layers; ++l) {
     const bf16_t* em = w.emod + (size_t)l * nF * 6 * d;  // [nF][6][d]
     bf16_t* kc = (bf16_t*)k_cache + (size_t)l * layer_stride;
@@ -394,6 +438,7 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
       a.q_prescaled = prescale_q;
       a.split_ws = (float*)w.xn;                    // norm1's output is dead once the QKV GEMM has consumed it
       a.split_ws_bytes = (size_t)Lq * d * sizeof(bf16_t);
+      a.redo_stats = h->attn_stats;
       ProfScope ps(K_ATTN_SELF, 4.0 * Lq * (double)np * S * d, s);
       HIP_TRY(mmpl_launch_attention(a, s), "self attention");
     }
@@ -415,6 +460,7 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
       a.n_pages = 1;
       a.cross = 1;
       if (cross_w64) { a.variant = ATTN_W64; a.q_prescaled = true; }
+      else if (ctx_n >= 0) { a.page_rows = ctx_n + 1; a.last_row_copies = T - ctx_n; }   // padded tail = one key, weighted (precompute_context)
       a.k_pages[0] = (const bf16_t*)cross_k + (size_t)l * T * d;
       a.v_pages[0] = (const bf16_t*)cross_v + (size_t)l * T * d;
       ProfScope ps(K_ATTN_CROSS, 4.0 * Lq * (double)T * d, s);
@@ -514,11 +560,6 @@ int mmpl_gemm_scratch(const void* A, int lda, const void* W, int ldw, const void
   if ((epi == EPI_GATE_RES && (!res || !gate)) || (epi == EPI_RES && !res)) return fail("mmpl_gemm", "missing epilogue operand");
   if (!scratch || scratch_bytes < mmpl_gemm_scratch_bytes()) return fail("mmpl_gemm_scratch", "scratch missing or smaller than mmpl_gemm_scratch_bytes()");
   if (reinterpret_cast<uintptr_t>(scratch) % 256) return fail("mmpl_gemm_scratch", "scratch must be 256-byte aligned");
-  {
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing((hipStream_t)stream, &st);
-    mmpl_xcd_dispatch_ok(st == hipStreamCaptureStatusNone);          // the once-per-device probe synchronises: never inside a capture
-  }
   return gemm((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (bf16_t*)C, ldc, M, N, K, epi,
               (const bf16_t*)res, ldres, (const bf16_t*)gate, gate_frame_stride, rows_per_frame, (hipStream_t)stream, (int*)scratch,
               (float*)((char*)scratch + 2048));

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
   const float c = a.scale * 1.4426950408889634f;  // fold log2(e): p = exp2(s*c - m*c)
+  const float last_bias = a.last_row_copies > 1 ? __logf((float)a.last_row_copies) / a.scale : 0.f;
 
   // per-lane LDS read offsets
   const int k_off = l31 * K_STRIDE + 16 * hi;                                          // + 32*c bytes, + 32 rows for half 1
@@ -168,6 +169,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs a) {
         const int kv = 8 * (r >> 2) + 4 * hi + (r & 3);
         if (kv >= valid) s0[r] = -INFINITY;
         if (kv + 32 >= valid) s1[r] = -INFINITY;
+      }
+    }
+    // the page's last row stands for `last_row_copies` identical keys (the zero-padded tail of the text context, api.hip):
+    // copies * exp(scale * s) = exp(scale * (s + ln(copies) / scale))
+    if (last_bias != 0.f && valid <= KVB) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kv = 8 * (r >> 2) + 4 * hi + (r & 3);
+        if (kv == valid - 1) s0[r] += last_bias;
+        if (kv + 32 == valid - 1) s1[r] += last_bias;
       }
     }
     float mx = s0[0];
@@ -351,6 +362,7 @@ hipError_t mmpl_launch_attention(const AttnArgs& a_in, hipStream_t s) {
     if (variant == ATTN_W64 && !a.q_prescaled) variant = ATTN_LOCKSTEP;
   }
   if (a.q_prescaled && variant != ATTN_W64) return hipErrorInvalidValue;
+  if (a.last_row_copies > 1 && (variant != ATTN_LOCKSTEP || a.n_pages != 1)) return hipErrorInvalidValue;
   const int n_qb = (a.Lq + QB - 1) / QB;
   if (variant == ATTN_LOCKSTEP) {
     const void* f = a.cross ? reinterpret_cast<const void*>(attn_fwd_kernel<1>) : reinterpret_cast<const void*>(attn_fwd_kernel<0>);

@@ -58,13 +58,30 @@ constexpr int AO = 0, AQ = 128, AV = 192;      // accumulator-file map
 #ifndef W64_ABL
 #define W64_ABL 0
 #endif
+// Dev timing mock (tools/gen_attn_w64_mock16.py, results are garbage): -DW64_MOCK16=1 issues every MFMA of the loop as two
+// v_mfma_f32_16x16x32_bf16 on the same operand registers (accumulator chains as long as a native 16-wide kernel's) with the fillers
+// scheduled into 128 gaps of 16 cycles.  0 in every shipped build.
+#ifndef W64_MOCK16
+#define W64_MOCK16 0
+#endif
+#if W64_MOCK16
+#define SREG(X, h, e) S4[X][h][(e) >> 2][(e) & 3]
+#define MREG(h, r) M4[h][(r) >> 2][(r) & 3]
+#else
+#define SREG(X, h, e) S[X][h][e]
+#define MREG(h, r) M[h][r]
+#endif
 
 // All state of a wave.  Passed by reference through always-inlined members, so every field ends up in a register (VGPR or,
 // when provably wave-uniform, SGPR); arrays are only ever indexed with compile-time constants.
 struct Ctx {
   // ---- vector state
+#if W64_MOCK16
+  f32x4 S4[2][2][4], M4[2][4];
+#else
   f32x16 S[2][2];        // [query block][kv half]
   f32x16 M[2];           // [kv half] C operand of a score tile's first MFMA: 0, or -inf on the rows past a page's end
+#endif
   u32x4 P[2][4];         // [query block][16-row kv step]: 8 bf16 = B operand of O^T += V^T.P^T
   bf16x8 kf[16];         // K fragments of one tile: i = 2*chunk + half
   float l[2], mref[2];   // running row sum (this lane's 32 kv columns of every tile) and reference (log2 units)
@@ -89,6 +106,7 @@ struct Ctx {
   unsigned long long ticks;                    // W64_ABL & 16: shader cycles of the pass's steady loop
 
   // ---------------------------------------------------------------- MFMAs
+#if !W64_MOCK16
   template <int X, int G> MMPL_DEV void mfma_qk() {      // S_X[h] (+)= K frag G . Q_X[chunk]
     constexpr int c = G >> 1, h = G & 1, qa = AQ + 32 * X + 4 * c;
     if constexpr (c == 0)
@@ -96,15 +114,25 @@ struct Ctx {
     else
       asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(S[X][h]) : "v"(kf[G]), "i"(qa), "i"(qa + 3));
   }
+#else
+  // mock: the score FLOPs of MFMA (X, G) as two 16x16x32; S register group 2 (c & 1) + HALF of S_X[h] collects the 4 chunks of its parity
+  template <int X, int G, int HALF> MMPL_DEV void mfma_qk_h() {
+    constexpr int c = G >> 1, h = G & 1, qa = AQ + 32 * X + 4 * c, grp = 2 * (c & 1) + HALF;
+    if constexpr (c < 2)
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, a[%c2:%c3], %4" : "=&v"(S4[X][h][grp]) : "v"(kf[G]), "i"(qa), "i"(qa + 3), "v"(M4[h][grp]));
+    else
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(S4[X][h][grp]) : "v"(kf[G]), "i"(qa), "i"(qa + 3));
+  }
+#endif
   template <int X, int G> MMPL_DEV void mfma_pv() {      // O_X[nb] += V frag G . P_X[ks]
     constexpr int ks = G >> 2, nb = G & 3, oa = AO + 64 * X + 16 * nb, va = AV + 4 * G;
     asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], a[%c2:%c3], %4, a[%c0:%c1]" ::"i"(oa), "i"(oa + 15), "i"(va), "i"(va + 3),
                  "v"(P[X][ks]));
   }
-  // dev timing mock (-DW64_ABL=256 + W64_PVSPLIT=1 schedule; garbage results): the PV FLOPs as two 16x16x32 MFMAs per 32x32x16 one,
-  // the gap's fillers split around the second -- what would the other instruction shape buy in this loop?
+  // dev timing mocks (garbage results): the PV FLOPs as two 16x16x32 MFMAs per 32x32x16 one (-DW64_ABL=256 + W64_PVSPLIT=1 schedule, or
+  // the whole loop with -DW64_MOCK16=1); O register group 2 (ks & 1) + HALF of O_X[nb]: two MFMAs per group and KV tile, as in a native kernel
   template <int X, int G, int HALF> MMPL_DEV void mfma_pv_h() {
-    constexpr int ks = G >> 2, nb = G & 3, oa = AO + 64 * X + 16 * nb + 8 * HALF, va = AV + 4 * G;
+    constexpr int ks = G >> 2, nb = G & 3, oa = AO + 64 * X + 16 * nb + 4 * (2 * (ks & 1) + HALF), va = AV + 4 * G;
     asm volatile("v_mfma_f32_16x16x32_bf16 a[%c0:%c1], a[%c2:%c3], %4, a[%c0:%c1]" ::"i"(oa), "i"(oa + 3), "i"(va), "i"(va + 3), "v"(P[X][ks]));
   }
   // ---------------------------------------------------------------- LDS fragment reads
@@ -207,7 +235,7 @@ struct Ctx {
     sfor<32>([self, hi4, ninf, zero, valid](auto ii) {
       constexpr int i = decltype(ii)::value, h = i >> 4, r = i & 15;
       const int thr = valid - (32 * h + 8 * (r >> 2) + (r & 3));          // masked iff 4 hi >= thr
-      asm volatile("v_cmp_le_i32 vcc, %2, %1\n\tv_cndmask_b32 %0, %4, %3, vcc" : "=v"(self->M[h][r]) : "v"(hi4), "s"(thr), "v"(ninf), "v"(zero) : "vcc");
+      asm volatile("v_cmp_le_i32 vcc, %2, %1\n\tv_cndmask_b32 %0, %4, %3, vcc" : "=v"(self->MREG(h, r)) : "v"(hi4), "s"(thr), "v"(ninf), "v"(zero) : "vcc");
     });
     masked = 1;
   }
@@ -215,7 +243,7 @@ struct Ctx {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) M[h][r] = 0.f;
+      for (int r = 0; r < 16; ++r) MREG(h, r) = 0.f;
     masked = 0;
   }
   MMPL_DEV int plan(int j) {
@@ -259,9 +287,9 @@ struct Ctx {
     if constexpr (W64_ABL & (2 | 32)) return;
     constexpr int h = Q >> 3, e = (Q & 7) * 2 + EL;
     if constexpr (MODE == 0)
-      asm volatile("v_exp_f32 %0, %1" : "=v"(t[X][Q & 1][EL]) : "v"(S[X][h][e]));
+      asm volatile("v_exp_f32 %0, %1" : "=v"(t[X][Q & 1][EL]) : "v"(SREG(X, h, e)));
     else
-      asm volatile("v_sub_f32 %0, %1, %2\n\tv_exp_f32 %0, %0" : "=&v"(t[X][Q & 1][EL]) : "v"(S[X][h][e]), "v"(mref[X]));
+      asm volatile("v_sub_f32 %0, %1, %2\n\tv_exp_f32 %0, %0" : "=&v"(t[X][Q & 1][EL]) : "v"(SREG(X, h, e)), "v"(mref[X]));
   }
   template <int MODE, int X, int Q> MMPL_DEV void sm_e0() { sm_e<MODE, X, Q, 0>(); }
   template <int MODE, int X, int Q> MMPL_DEV void sm_e1() { sm_e<MODE, X, Q, 1>(); }
@@ -282,11 +310,11 @@ struct Ctx {
   }
   // GENERAL pass, slow path of one tile of stream X (see the header): returns the tile's partial row sum.
   template <int X> MMPL_DEV float slow(float lt) {
-    float mx = S[X][0][0];
+    float mx = SREG(X, 0, 0);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[X][0][r]);
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, SREG(X, 0, r));
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[X][1][r]);
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, SREG(X, 1, r));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     if (first[X]) {
       first[X] = 0;
@@ -308,8 +336,8 @@ struct Ctx {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int h = q >> 3, e = (q & 7) * 2;
-      const float a0 = __builtin_amdgcn_exp2f(S[X][h][e] - mref[X]);
-      const float a1 = __builtin_amdgcn_exp2f(S[X][h][e + 1] - mref[X]);
+      const float a0 = __builtin_amdgcn_exp2f(SREG(X, h, e) - mref[X]);
+      const float a1 = __builtin_amdgcn_exp2f(SREG(X, h, e + 1) - mref[X]);
       lt += a0 + a1;
       P[X][q >> 2][q & 3] = pack2bf(a0, a1);
     }
@@ -324,7 +352,11 @@ struct Ctx {
   }
 };
 
+#if W64_MOCK16
+#include "attn_w64_sched16.inc"
+#else
 #include "attn_w64_sched.inc"
+#endif
 
 // One pass over the block's KV tiles in softmax mode MODE (0 FAST, 1 GENERAL): O in a[0:127], row sums in la / lb (FAST) or l
 // (GENERAL), references in mref.
@@ -471,11 +503,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const float l_tot = k.l[X] + __shfl_xor(k.l[X], 32, 64);
       bad |= !(l_tot >= FAST_L_MIN && l_tot <= FAST_L_MAX);
     }
-    if constexpr (W64_ABL != 0) bad = false;
+    if constexpr (W64_ABL != 0 || W64_MOCK16) bad = false;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // the parked cursors' last re-fetches
     if (__any(bad) && lane == 0) *redo = 1;
     __syncthreads();
-    if (*redo) w64_pass<1>(k);
+    const int redo_block = *redo;
+    if (a.redo_stats && tid == 0) {
+      atomicAdd(a.redo_stats, 1ull);
+      if (redo_block) atomicAdd(a.redo_stats + 1, 1ull);
+    }
+    if (redo_block) w64_pass<1>(k);
   }
 
   // ---- epilogue: lane (q = l31, hi) holds O_X[q][32*nb + 8*g + 4*hi + {0..3}] in a[64 X + 16 nb + 4 g ..+3]

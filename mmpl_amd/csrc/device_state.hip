@@ -23,10 +23,9 @@ __global__ void xcc_probe_kernel(int* out) {
 }
 }  // namespace
 
-// Workgroups of a launch are dealt round-robin to the 8 XCDs.  The tile / head orders only rely on that for L2 locality, but the
-// split-K GEMM launch relies on it for VISIBILITY (the parts of a tile exchange fp32 partials through their XCD's L2 without a
-// device-scope write-back), so it is checked on the hardware, once per device, outside any stream capture (mmpl_dit_create,
-// mmpl_gemm_scratch); until / unless the check has passed, no GEMM is split.
+// Workgroups of a launch are dealt round-robin to the 8 XCDs.  The tile / head orders rely on that for L2 LOCALITY only: since
+// round 4 nothing relies on it for visibility (the split-K GEMM launch exchanges its partials with system-scope accesses,
+// gemm.hip).  The probe stays as a diagnostic (C ABI mmpl_device_xcd_round_robin): once per device, outside any stream capture.
 bool mmpl_xcd_dispatch_ok(bool may_probe) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
@@ -37,14 +36,16 @@ bool mmpl_xcd_dispatch_ok(bool may_probe) {
     int h[n];
     bool ok = hipMalloc(&d, n * sizeof(int)) == hipSuccess;
     if (ok) {
+      ok = hipMemset(d, 0xff, n * sizeof(int)) == hipSuccess;
       hipLaunchKernelGGL(xcc_probe_kernel, dim3(n), dim3(64), 0, 0, d);
-      ok = hipMemcpy(h, d, n * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+      ok = ok && hipGetLastError() == hipSuccess;
+      ok = hipMemcpy(h, d, n * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && ok;
       (void)hipFree(d);
     }
     unsigned seen = 0;
     for (int x = 0; ok && x < 8; ++x) {
-      ok = !(seen & (1u << h[x]));                              // 8 residues, 8 different XCCs
-      seen |= 1u << h[x];
+      ok = h[x] >= 0 && h[x] < 8 && !(seen & (1u << h[x]));     // 8 residues, 8 different XCCs
+      if (ok) seen |= 1u << h[x];
     }
     for (int b = 8; ok && b < n; ++b) ok = h[b] == h[b & 7];
     g_xcd_dispatch[dev] = ok ? 1 : -1;
@@ -85,7 +86,7 @@ const MmplRuntimeConfig& mmpl_config() {
     auto num = [](const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; };
     MmplRuntimeConfig c{};
     c.attn_v1 = flag("MMPL_ATTN_V1"); c.attn_nosplit = flag("MMPL_ATTN_NOSPLIT"); c.attn_no_merge = flag("MMPL_ATTN_NO_MERGE");
-    c.cross_w64 = flag("MMPL_CROSS_W64");
+    c.cross_w64 = flag("MMPL_CROSS_W64"); c.cross_no_collapse = flag("MMPL_CROSS_NO_COLLAPSE");
     c.gemm_v1 = flag("MMPL_GEMM_V1"); c.gemm_v2 = flag("MMPL_GEMM_V2"); c.gemm_direct_epilogue = flag("MMPL_GEMM_DIRECT_EPILOGUE");
     c.gemm_static_tiles = flag("MMPL_GEMM_STATIC_TILES"); c.gemm_no_sync_sweeps = flag("MMPL_GEMM_NO_SYNC_SWEEPS");
     c.gemm_no_splitk = flag("MMPL_GEMM_NO_SPLITK");

@@ -318,6 +318,24 @@ hipError_t mmpl_launch_unpatchify(const bf16_t* y, int ldy, bf16_t* out, int F, 
   hipLaunchKernelGGL(unpatchify_kernel, dim3(grid_for(n)), dim3(256), 0, s, y, ldy, out, F, C, h, w);
   return hipGetLastError();
 }
+// flags[r] = 1 iff row r of x ([rows, d] bf16, d % 8 == 0) is bitwise identical to row rows - 1 (one wave per row)
+__global__ __launch_bounds__(64) void rows_equal_last_kernel(const bf16_t* x, int ld, int rows, int d, int* flags) {
+  const int r = blockIdx.x;
+  const u32x4* a = reinterpret_cast<const u32x4*>(x + (size_t)r * ld);
+  const u32x4* b = reinterpret_cast<const u32x4*>(x + (size_t)(rows - 1) * ld);
+  bool same = true;
+  for (int i = threadIdx.x; i < d / 8; i += 64) {
+    const u32x4 u = a[i], v = b[i];
+    same = same && u[0] == v[0] && u[1] == v[1] && u[2] == v[2] && u[3] == v[3];
+  }
+  const bool all = __all(same);
+  if (threadIdx.x == 0) flags[r] = all ? 1 : 0;
+}
+hipError_t mmpl_launch_rows_equal_last(const bf16_t* x, int ld, int rows, int d, int* flags, hipStream_t s) {
+  if (d % 8 || ld % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(rows_equal_last_kernel, dim3(rows), dim3(64), 0, s, x, ld, rows, d, flags);
+  return hipGetLastError();
+}
 __global__ void zero_ints_kernel(int* p, int n) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
 }

@@ -478,6 +478,27 @@ MMPL_DEV void gemm_epilogue_staged(const GemmArgs& g, const f32x4 (&acc)[2][4][4
   }
 }
 
+// 16-byte system-scope accesses of the split-K partials: written through past the L2, read past L1 and L2 (valid between any two
+// CUs of the device whatever XCDs they sit on).  Asm because hipcc has no 16-byte atomic-scope access; the loads carry their own
+// wait (hipcc does not count asm loads, cdna_hip_programming.md 5.7 item 1), the store's s_nop keeps its data registers intact.
+MMPL_DEV void store16_sys(f32x4* p, const f32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+MMPL_DEV void load16x8_sys(const f32x4* p, f32x4 (&v)[8]) {      // rows p, p + 64, ... p + 448 (1 KiB apart)
+  asm volatile("global_load_dwordx4 %0, %8, off sc0 sc1\n\t"
+               "global_load_dwordx4 %1, %8, off offset:1024 sc0 sc1\n\t"
+               "global_load_dwordx4 %2, %8, off offset:2048 sc0 sc1\n\t"
+               "global_load_dwordx4 %3, %8, off offset:3072 sc0 sc1\n\t"
+               "global_load_dwordx4 %4, %9, off sc0 sc1\n\t"
+               "global_load_dwordx4 %5, %9, off offset:1024 sc0 sc1\n\t"
+               "global_load_dwordx4 %6, %9, off offset:2048 sc0 sc1\n\t"
+               "global_load_dwordx4 %7, %9, off offset:3072 sc0 sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+               : "v"(p), "v"(p + 256)
+               : "memory");
+}
+
 #ifndef GEMM6_TIMING
 #define GEMM6_TIMING 0      // dev: 1 = every wave leaves { prologue, k loop, epilogue } shader cycles over the output (tools/bench_kernels.py gemmphases)
 #endif
@@ -669,11 +690,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const size_t part_floats = (size_t)8 * 32 * 64 * 4;
     f32x4* wsp = reinterpret_cast<f32x4*>(g.splitk_ws + ((size_t)slot * g.splitk_s + part) * part_floats) + (size_t)wave * 32 * 64 + lane;
 #pragma unroll
-    for (int r = 0; r < 32; ++r) wsp[r * 64] = acc[r >> 4][(r >> 2) & 3][r & 3];
-    // Every part of a tile runs on the tile's XCD (slot lists are per XCD, blocks are dealt round-robin: mmpl_xcd_dispatch_ok()
-    // checks that once per device), so the partials only have to reach THAT L2: stores are write-through and acknowledged by the
-    // L2 (vmcnt), the ticket is an L2 atomic, and this CU has not read the partial area in this launch (one block per CU, L1
-    // invalidated at the dispatch).  A device-scope fence here would write back the whole L2 -- measured: +60 us per GEMM.
+    for (int r = 0; r < 32; ++r) store16_sys(wsp + r * 64, acc[r >> 4][(r >> 2) & 3][r & 3]);
+    // PLACEMENT-INDEPENDENT exchange (round 4; MI355X_MICROARCH.md "inter-workgroup visibility", form {sc0 sc1 stores and loads on
+    // both sides}): the partials are written through to memory past the writer's L2 (which drops the lines) and read back past
+    // the reader's L1 / L2, the ticket is an agent-scope atomic behind the drained stores.  Nothing here depends on which XCD a
+    // part runs on any more -- round 3 relied on "workgroup b runs on XCD b & 7" (probed once, on an idle device) for VISIBILITY;
+    // a CU mask, another queue or a second process sharing the GPU would have made the last part sum stale L2 lines.  The tile
+    // order still puts the parts of a tile on one XCD, for speed only.  A device-scope release fence instead of write-through
+    // stores writes back the whole L2: +60 us per GEMM (profiles/r03S_gemm_splitk_device_fence_ab_rejected.log).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the partial stores (and group B's prefetch DMAs into this block's LDS)
     __syncthreads();
     if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(g.splitk_cnt + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -681,16 +705,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (s_ticket != g.splitk_s - 1) return;                         // block-uniform
     if (threadIdx.x == 0) g.splitk_cnt[slot] = 0;                    // every other part of the tile has left: zero for the next launch
     const f32x4* rsp = reinterpret_cast<const f32x4*>(g.splitk_ws + (size_t)slot * g.splitk_s * part_floats) + (size_t)wave * 32 * 64 + lane;
+    // summed IN PART ORDER whoever is last (part 0 first, this block's own partial re-read like the others: same bits either way)
+    for (int p = 0; p < g.splitk_s; ++p) {
 #pragma unroll
-    for (int r = 0; r < 32; ++r) acc[r >> 4][(r >> 2) & 3][r & 3] = rsp[r * 64];
-    for (int p = 1; p < g.splitk_s; ++p) {
-      rsp += part_floats / 4;
+      for (int r0 = 0; r0 < 32; r0 += 8) {
+        f32x4 v[8];
+        load16x8_sys(rsp + r0 * 64, v);
 #pragma unroll
-      for (int r = 0; r < 32; ++r) {
-        const f32x4 v = rsp[r * 64];
-        f32x4& a = acc[r >> 4][(r >> 2) & 3][r & 3];
-        a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+        for (int i = 0; i < 8; ++i) {
+          const int r = r0 + i;
+          f32x4& a = acc[r >> 4][(r >> 2) & 3][r & 3];
+          if (p == 0) a = v[i];
+          else { a[0] += v[i][0]; a[1] += v[i][1]; a[2] += v[i][2]; a[3] += v[i][3]; }
+        }
       }
+      rsp += part_floats / 4;
     }
   }
   if constexpr (GEMM6_ABL & 2) {
@@ -762,7 +791,7 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
   // at about half the usual rate and the partials' round trip is ~15 us, so short-K GEMMs lose (K = 1536: -9...-23 %; K = 5120:
   // +1...+10 %; K = 8960 / 13824: +14...+58 %, profiles/r03S_gemm_splitk_micro.log).
   g2.splitk_s = 1; g2.splitk_tb = 0; g2.splitk_per = per;
-  if (g2.tile_counter && g.splitk_ws && g.splitk_cnt && !rc.gemm_no_splitk && EPI != EPI_F32_SCALE && g.K / BK4 >= 64 && mmpl_xcd_dispatch_ok(false)) {
+  if (g2.tile_counter && g.splitk_ws && g.splitk_cnt && !rc.gemm_no_splitk && EPI != EPI_F32_SCALE && g.K / BK4 >= 64) {
     const int tiles_n_ = (g.N + BN3 - 1) / BN3, per_group = g2.group * tiles_n_;
     const int dealt = g2.sync_sweeps ? ((tiles_m_ / g2.group) >> 3) * per_group : 0, left = tiles - 8 * dealt;
     int tb = 0, main_tiles = 0;

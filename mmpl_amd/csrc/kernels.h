@@ -60,6 +60,12 @@ struct AttnArgs {
   float* split_ws; size_t split_ws_bytes;   // optional scratch for the split-KV tail round (nullptr: never split)
   int variant;                     // ATTN_* kernel selector (0 = auto)
   int q_prescaled;                 // q was already multiplied by scale * log2(e) by its producer (ATTN_W64 only)
+  // attn_fwd_kernel with ONE page only: the page's last row stands for `last_row_copies` identical keys (same K row, same V row):
+  // its score gets + ln(copies) / scale, i.e. its softmax weight is multiplied by copies.  0 / 1 = a plain row.
+  int last_row_copies;
+  // attn_w64_kernel, optional: two device counters {blocks run, blocks whose FAST pass failed and were redone by the GENERAL pass}
+  // (one atomic per block; how data-dependent is the kernel's time on THIS input? -- bench.py --heavy-tail)
+  unsigned long long* redo_stats;
 };
 // Work item `local` of XCD `xcd` -> (head, query block) for attn_w64_kernel / attn_merge_kernel (the hardware deals workgroups
 // round-robin to the 8 XCDs: blockIdx & 7).  H % 8 == 0: XCD x owns heads x, x+8, ...; any other head count (Wan 1.3B: 12):
@@ -135,6 +141,8 @@ hipError_t mmpl_launch_add(bf16_t* a, const bf16_t* b, size_t n, hipStream_t s);
 hipError_t mmpl_launch_unpatchify(const bf16_t* y, int ldy, bf16_t* out, int F, int C, int h, int w, hipStream_t s);
 // sinusoidal timestep embedding (fp64 math): t[F] fp32 -> out[F, freq_dim] bf16 ([cos | sin])
 hipError_t mmpl_launch_zero_ints(int* p, int n, hipStream_t s);
+// flags[r] = (row r of x[rows, d] == row rows - 1, bitwise)
+hipError_t mmpl_launch_rows_equal_last(const bf16_t* x, int ld, int rows, int d, int* flags, hipStream_t s);
 hipError_t mmpl_launch_sinusoid(const float* t, bf16_t* out, int F, int freq_dim, hipStream_t s);
 hipError_t mmpl_launch_silu(const bf16_t* x, bf16_t* y, size_t n, hipStream_t s);
 

@@ -6,6 +6,7 @@
 //   MMPL_ATTN_NOSPLIT=1          no split-KV tail round
 //   MMPL_ATTN_NO_MERGE=1         do not merge contiguous KV pages into longer ones
 //   MMPL_CROSS_W64=1             text / image cross-attention on attn_w64_kernel
+//   MMPL_CROSS_NO_COLLAPSE=1     text cross-attention over all text_len keys even when the context's padded tail is one repeated row
 //   MMPL_GEMM_V1=1 / _V2=1       every GEMM on the 128x128 register-staged / the 256x128 3-stage-DMA kernel
 //   MMPL_GEMM_GROUP=n            M-tile group of v6's tile order (default: per shape)
 //   MMPL_GEMM_PF=n               v6's L2 prefetch distance in k-tiles (default 2; 0 = off)
@@ -17,7 +18,7 @@
 #pragma once
 
 struct MmplRuntimeConfig {
-  bool attn_v1, attn_nosplit, attn_no_merge, cross_w64;
+  bool attn_v1, attn_nosplit, attn_no_merge, cross_w64, cross_no_collapse;
   bool gemm_v1, gemm_v2, gemm_direct_epilogue, gemm_static_tiles, gemm_no_sync_sweeps, gemm_no_splitk;
   int gemm_group;      // 0 = launcher's choice
   int gemm_pf;         // k-tiles

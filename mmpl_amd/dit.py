@@ -104,6 +104,25 @@ class DitEngine:
                 layers=[[g(f"blocks.{i}.cross_attn." + k) for k in ("k_img.weight", "k_img.bias", "v_img.weight", "v_img.bias",
                                                                      "norm_k_img.weight")] for i in range(self.L)])
 
+    # ------------------------------------------------------------------ diagnostics
+    def enable_attn_stats(self) -> torch.Tensor:
+        """Count the self-attention kernel's query blocks and how many of them the max-free FAST softmax pass could not hold
+        (redone by the GENERAL pass): int64 [2] on the device = {blocks, blocks redone}, incremented by every forward (hipGraph
+        replays too) until `disable_attn_stats`.  One atomic per 256-row block: not measurable in the step time."""
+        if getattr(self, "_attn_stats", None) is None:
+            self._attn_stats = torch.zeros(2, dtype=torch.int64, device=self.device)
+        _lib.check(self._lib.mmpl_dit_set_attn_stats(self._h, _lib.ptr(self._attn_stats)), "mmpl_dit_set_attn_stats")
+        return self._attn_stats
+
+    def disable_attn_stats(self) -> None:
+        _lib.check(self._lib.mmpl_dit_set_attn_stats(self._h, None), "mmpl_dit_set_attn_stats")
+
+    def read_attn_stats(self, reset: bool = False) -> Tuple[int, int]:
+        blocks, redone = (int(v) for v in self._attn_stats.cpu())
+        if reset:
+            self._attn_stats.zero_()
+        return blocks, redone
+
     # ------------------------------------------------------------------ caches
     def new_kv_cache(self, n_slots: int = 15) -> Tuple[torch.Tensor, torch.Tensor]:
         """[num_layers, n_slots*S, dim] K and V; layer l is the reference's kv_cache[l]['k'] viewed [1, n_slots*S, H, 128]

@@ -124,9 +124,22 @@ class CfgPair:
 
 class ChunkHandoff:
     """Point-to-point anchor exchange between the ranks of one node (or of `group`, e.g. the lane heads of a CFG-split
-    layout; ranks inside the group are translated to global ranks for the p2p calls)."""
+    layout; ranks inside the group are translated to global ranks for the p2p calls).
 
-    def __init__(self, shape: Sequence[int], device, group=None):
+    Ready handshake (round 4).  An RCCL send is a KERNEL that spins on the sender's GPU until the peer's matching recv kernel
+    runs.  In the wavefront the consumer of chunk c + 1 is usually already waiting (lanes >= the ~3.1 chunks the wavefront keeps
+    busy), but on wrap-around with few lanes (n_chunks > lanes: BASELINE configs[4], or 2 GPUs) it is still computing its
+    previous chunk when the producer's anchor stage ends -- the send kernel would then sit on a CU for minutes next to kernels
+    that assume one workgroup per CU (attn_w64_kernel: 128 KiB of LDS and all 512 registers of every SIMD; the GEMM's tile
+    tickets).  So the DATA goes over RCCL, but WHEN it is issued is agreed on the host: the consumer announces "ready for
+    chunk c" (an 8-byte gloo message on a side group) right before it posts its recv; the producer issues the send only
+    once that announcement has arrived -- at the sink if it already has, else at the next poll point (the pipeline calls
+    `poll()` between stages, `run_chunk_wavefront` drains with a blocking wait after the chunk).  Either way a send kernel is
+    only ever launched against a recv that is already posted: it occupies one CU for the microseconds the 3.7 MB take.
+    Chunk order makes the blocking drain deadlock-free: the wait is for the consumer to finish an EARLIER chunk.
+    `stats[c]` keeps wall-clock stamps (time.time(), one host) of every hand-off for bench.py's wavefront report."""
+
+    def __init__(self, shape: Sequence[int], device, group=None, ready_handshake: bool = True):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -138,54 +151,143 @@ class ChunkHandoff:
         self._g = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
         self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self._pending: List = []
+        self._deferred: List = []              # [(chunk, hdr, payload, ready request)] hand-offs whose consumer is not ready yet
+        self._ready_req = {}                   # consumer chunk -> irecv request of its "ready" announcement
+        self._keep: List = []                  # control tensors / requests that must outlive their call
+        self.stats = {}
+        self.handshake = ready_handshake and self.world > 1
+        self._ctl = None
+        if self.handshake:
+            # control plane: gloo.  The data group itself when it is gloo (CPU tests, shared-GPU functional runs); else a gloo
+            # group over the same ranks, created by its members only (use_local_synchronization: non-members do not take part)
+            if self.backend == "gloo":
+                self._ctl = group
+            else:
+                ranks = [self._g(r) for r in range(self.world)]
+                self._ctl = dist.new_group(ranks, backend="gloo", use_local_synchronization=True)
 
     def owner(self, chunk: int) -> int:
         return chunk % self.world
 
-    def send(self, chunk: int, tensor: Optional[torch.Tensor], status: int = OK) -> None:
-        """Send chunk `chunk`'s hand-off to the owner of chunk+1 (asynchronous; overlaps the caller's next stage)."""
-        dst_local = self.owner(chunk + 1)
-        dst = self._g(dst_local)
-        hdr = torch.tensor([status, chunk], dtype=torch.int64, device=self.device)
-        payload = (torch.zeros(self.shape, dtype=torch.bfloat16, device=self.device) if tensor is None
-                   else tensor.detach().to(device=self.device, dtype=torch.bfloat16).reshape(self.shape).contiguous())
-        if dst_local == self.rank:                             # world size 1 (or wrap onto ourselves): local hand-over
-            self._local = (hdr, payload)
+    # ---- ready handshake (host side, gloo)
+    def expect_ready(self, chunk: int) -> None:
+        """Producer of `chunk - 1`: post the receive of the consumer's "ready for `chunk`" announcement (returns at once)."""
+        if not self.handshake or self.owner(chunk) == self.rank or chunk in self._ready_req:
             return
+        buf = torch.zeros(1, dtype=torch.int64)
+        self._ready_req[chunk] = (self.dist.irecv(buf, self._g(self.owner(chunk)), group=self._ctl, tag=_READY_TAG + chunk), buf)
+
+    def announce_ready(self, chunk: int) -> None:
+        """Consumer of `chunk`: tell the producer of chunk - 1 that the recv is about to be posted."""
+        import time
+        self.stats.setdefault(chunk, {})["t_ready"] = time.time()
+        if not self.handshake or self.owner(chunk - 1) == self.rank:
+            return
+        buf = torch.tensor([chunk], dtype=torch.int64)
+        self._keep.append((self.dist.isend(buf, self._g(self.owner(chunk - 1)), group=self._ctl, tag=_READY_TAG + chunk), buf))
+
+    def _consumer_ready(self, chunk: int, block: bool) -> bool:
+        if not self.handshake:
+            return True
+        if chunk not in self._ready_req:
+            self.expect_ready(chunk)
+        req, _ = self._ready_req[chunk]
+        if block:
+            req.wait()
+            return True
+        return bool(req.is_completed())
+
+    def _issue(self, chunk: int, hdr: torch.Tensor, payload: torch.Tensor) -> None:
+        import time
+        dst = self._g(self.owner(chunk + 1))
+        self.stats.setdefault(chunk + 1, {})["t_issued"] = time.time()
         if self._side is not None:
             self._side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self._side):
                 self._pending += [self.dist.isend(hdr, dst, group=self.group, tag=2 * chunk),
                                   self.dist.isend(payload, dst, group=self.group, tag=2 * chunk + 1)]
                 payload.record_stream(self._side)
+                hdr.record_stream(self._side)
         else:
             self._pending += [self.dist.isend(hdr, dst, group=self.group, tag=2 * chunk),
                               self.dist.isend(payload, dst, group=self.group, tag=2 * chunk + 1)]
+        self._keep.append((hdr, payload))
+
+    def send(self, chunk: int, tensor: Optional[torch.Tensor], status: int = OK) -> None:
+        """Hand chunk `chunk`'s anchors to the owner of chunk+1 (asynchronous; overlaps the caller's next stage).  Issued now if
+        the consumer has announced it is ready (or the handshake is off), otherwise at the next poll() / drain()."""
+        import time
+        dst_local = self.owner(chunk + 1)
+        now = time.time()
+        self.stats.setdefault(chunk + 1, {})["t_sink"] = now
+        hdr = torch.tensor([status, chunk, int(now * 1e6)], dtype=torch.int64, device=self.device)
+        payload = (torch.zeros(self.shape, dtype=torch.bfloat16, device=self.device) if tensor is None
+                   else tensor.detach().to(device=self.device, dtype=torch.bfloat16).reshape(self.shape).contiguous())
+        if dst_local == self.rank:                             # world size 1 (or wrap onto ourselves): local hand-over
+            self._local = (hdr, payload)
+            return
+        if payload.data_ptr() == (tensor.data_ptr() if tensor is not None else 0):
+            payload = payload.clone()                          # a deferred send must not alias a buffer the caller keeps writing
+        if self._consumer_ready(chunk + 1, block=False):
+            self._issue(chunk, hdr, payload)
+        else:
+            self._deferred.append((chunk, hdr, payload))
+
+    def poll(self) -> int:
+        """Issue the deferred hand-offs whose consumers have become ready (non-blocking); returns how many are still deferred."""
+        still = []
+        for chunk, hdr, payload in self._deferred:
+            if self._consumer_ready(chunk + 1, block=False):
+                self._issue(chunk, hdr, payload)
+            else:
+                still.append((chunk, hdr, payload))
+        self._deferred = still
+        return len(still)
+
+    def drain(self) -> None:
+        """Blocking: wait for every deferred hand-off's consumer and issue it (end of the producer's chunk)."""
+        for chunk, hdr, payload in self._deferred:
+            self._consumer_ready(chunk + 1, block=True)
+            self._issue(chunk, hdr, payload)
+        self._deferred = []
 
     def recv(self, chunk: int) -> torch.Tensor:
         """Receive the hand-off produced by chunk-1.  Blocks until the producer's anchor stage is done (minutes per lane at
         14B/720p), bounded only by the process group's timeout -- the entry points raise it from torch's 10-minute default
         to 12 h (mmpl_amd/cli.py) / 4 h (bench.py); raises if the producer reported failure."""
+        import time
         src_local = self.owner(chunk - 1)
         src = self._g(src_local)
+        self.announce_ready(chunk)
         if src_local == self.rank:
             hdr, payload = self._local
         else:
-            hdr = torch.zeros(2, dtype=torch.int64, device=self.device)
+            hdr = torch.zeros(3, dtype=torch.int64, device=self.device)
             payload = torch.empty(self.shape, dtype=torch.bfloat16, device=self.device)
             self.dist.recv(hdr, src, group=self.group, tag=2 * (chunk - 1))
             self.dist.recv(payload, src, group=self.group, tag=2 * (chunk - 1) + 1)
-        st, ck = [int(v) for v in hdr.tolist()]
+        st, ck, t_sink_us = [int(v) for v in hdr.tolist()]      # (.tolist() synchronises: the payload has landed too -- same stream)
+        rec = self.stats.setdefault(chunk, {})
+        rec["t_recv_done"] = time.time()
+        rec["t_sink"] = t_sink_us * 1e-6
         if st != OK or ck != chunk - 1:
             raise RuntimeError(f"hand-off for chunk {chunk}: producer rank {src} reported status {st} (chunk {ck})")
         return payload
 
     def flush(self) -> None:
+        self.drain()
         for w in self._pending:
             w.wait()
         self._pending.clear()
+        for item in self._keep:
+            if hasattr(item[0], "wait"):
+                item[0].wait()
+        self._keep.clear()
         if self._side is not None:
             torch.cuda.current_stream(self.device).wait_stream(self._side)
+
+
+_READY_TAG = 1 << 20
 
 
 def run_chunk_wavefront(make_chunk: Callable[[int, Optional[torch.Tensor], Callable[[torch.Tensor], None]], torch.Tensor],
@@ -216,10 +318,13 @@ def run_chunk_wavefront(make_chunk: Callable[[int, Optional[torch.Tensor], Calla
             sent[0] = True
 
         try:
+            if c + 1 < n_chunks:
+                handoff.expect_ready(c + 1)                    # the consumer's announcement may arrive any time from now on
             initial = to_initial(handoff.recv(c)) if c > 0 else None
             mine[c] = make_chunk(c, initial, sink)
             if not sent[0] and c + 1 < n_chunks:
                 raise RuntimeError(f"chunk {c} finished without producing its hand-off")
+            handoff.drain()                                    # a consumer that was still busy at the sink and at every poll since
         except Exception:
             if not sent[0] and c + 1 < n_chunks:
                 handoff.send(c, None, FAILED)                 # unblock the consumer with an error instead of a hang

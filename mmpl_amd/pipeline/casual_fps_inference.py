@@ -63,6 +63,9 @@ class CausalFPSInferencePipeline(torch.nn.Module):
         self.independent_first_frame = args.independent_first_frame
         self.local_attn_size = -1
         self.handoff_sink: Optional[Callable[[torch.Tensor], None]] = None
+        # called at every stage boundary after the hand-off stage (the host is in step with the GPU there): the multi-GPU runner
+        # installs ChunkHandoff.poll, which issues a deferred RCCL send once its consumer has announced it is ready (handoff.py)
+        self.handoff_poll: Optional[Callable[[], object]] = None
         self.renoise_override = None      # tests: {frame: [1,16,h,w]} instead of torch.randn_like draws
         self.use_graphs = True            # one hipGraph per (stage, cond|uncond) forward, replayed 50 + 1 times
         self.step_graphs = True           # ... and one per whole denoise step (2 forwards + CFG/UniPC) for the 50 steps
@@ -165,6 +168,9 @@ class CausalFPSInferencePipeline(torch.nn.Module):
 
             for si in range(first, len(stages)):
                 frames = stages[si]
+                if self.handoff_poll is not None and si > self.plan.handoff_stage:
+                    torch.cuda.synchronize(dev)                               # host in step with the GPU: the previous stage is done
+                    self.handoff_poll()
                 latents = noise[:, frames].contiguous()
                 if self.plan.renoised_frames(si):                             # :279-326
                     src = (3, 10) if si == 2 else (12, 19)

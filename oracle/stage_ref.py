@@ -73,12 +73,14 @@ def run_chunk(p: Dict[str, torch.Tensor], cfg: W.DitCfg, noise: torch.Tensor, ct
               ctx_uncond: torch.Tensor, renoise: Optional[Dict[int, torch.Tensor]] = None,
               initial_latent: Optional[torch.Tensor] = None, mode: str = "t2v", guidance: float = 5.0,
               steps: int = 50, shift: float = 5.0, attn_fn=W.sdpa, trace: Optional[list] = None,
-              gpu_scalar_semantics: bool = False, clip_fea: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None):
+              gpu_scalar_semantics: bool = False, clip_fea: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None,
+              last_stage: Optional[int] = None):
     """noise: [1, 21, 16, h, w]; renoise: {frame: [1,16,h,w]} replacements for frames 4,9,13,18 (t2v only);
     initial_latent: [1, 2, 16, h, w] or None.  Returns (output latents [1,21,16,h,w], hand-off tensor).
     clip_fea [257, clip_dim] and y [20, 21, h, w]: the Wan-I2V model type (p holds img_emb / k_img / v_img, cfg.in_dim 36) --
     every forward sees its frames of y concatenated to the latents on the channel axis (wan/modules/model.py:680-681) and
-    both CFG branches share clip_fea and y (wan/image2video.py:283-295)."""
+    both CFG branches share clip_fea and y (wan/image2video.py:283-295).
+    last_stage: stop after that stage (tests that only need the hand-off: it exists once the anchor stage is done)."""
     clean = T2V_CLEAN_STEPS if mode == "t2v" else I2V_CLEAN_STEPS
     stages = stage_frames(clean)
     S = (noise.shape[-2] // 2) * (noise.shape[-1] // 2)
@@ -140,6 +142,8 @@ def run_chunk(p: Dict[str, torch.Tensor], cfg: W.DitCfg, noise: torch.Tensor, ct
             handoff = (torch.cat([output[:, :1], latents], dim=1) if mode == "t2v"
                        else torch.cat([output[:, :1], output[:, -2:]], dim=1))
         refresh(latents, frames)                                                  # :385-403
+        if last_stage is not None and si >= last_stage:
+            break
     return output, handoff, caches
 
 

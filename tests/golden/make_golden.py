@@ -1,7 +1,7 @@
 """Generate golden fixtures by running the REAL reference (/root/reference, CPU, bf16) on seeded inputs.
 
 Build-container only (the reference never travels to the GPU box).  Usage:
-    python tests/golden/make_golden.py [dit] [chunk] [sched] [vae]
+    python tests/golden/make_golden.py [dit] [chunk] [chunk50] [sched] [vae]
 Writes tests/golden/*.pt.  Inputs are regenerated from seeds by the tests (mmpl_amd.synthetic), so the
 fixtures hold expected OUTPUTS of the reference (full or strided + sha256), plus known-answer scalars.
 While generating, the oracle restatement (oracle/) is run on the same inputs and its agreement with the
@@ -133,22 +133,41 @@ def gen_chunk(steps=2):
     ctx_c, ctx_u = make_context(cfg, 21, 40), make_context(cfg, 22, 12)
     noise = philox_normal([1, 21, 16, H, Wd], 23)
     renoise = {f: philox_normal([1, 16, H, Wd], 100 + f) for f in (4, 9, 13, 18)}
+    t0 = time.time()
+    output, handoff = _ref_stage_loop(m, fps, unipc, sched, cfg, noise.clone(), renoise, [ctx_c, ctx_u], steps)
+    print(f"[chunk] reference stage loop ({steps} steps/stage): {time.time() - t0:.1f}s")
+    t0 = time.time()
+    o_out, o_hand, _ = stage_ref.run_chunk(sd, ocfg, noise, ctx_c[0], ctx_u[0], renoise, None, "t2v", 5.0, steps, 5.0)
+    print(f"[chunk] oracle stage loop: {time.time() - t0:.1f}s  rel_l2 vs ref: out={rel_l2(o_out, output):.3e} "
+          f"handoff={rel_l2(o_hand, handoff):.3e}  out rms={output.float().pow(2).mean().sqrt().item():.3f}")
+    torch.save(dict(out_sha=sha(output), out_strided=output[..., ::2, ::2].clone(), handoff_sha=sha(handoff),
+                    handoff_strided=handoff[..., ::3, ::3].clone(),
+                    meta=dict(cfg="tiny", weight_seed=2, ctx_seeds=(21, 22), n_valid=(40, 12), noise_seed=23,
+                              renoise_seed_base=100, steps=steps, guidance=5.0, shift=5.0)),
+               os.path.join(HERE, "chunk_t2v_tiny.pt"))
+
+
+def _ref_stage_loop(m, fps, unipc, sched, cfg, noise, renoise, ctxs, steps, dtype=torch.bfloat16, progress=None):
+    """casual_fps_inference.py:250-403 re-enacted on the reference model + the reference UniPC, `steps` per stage."""
     kvs = [ref_caches(cfg), ref_caches(cfg)]
-    ctxs = [ctx_c, ctx_u]
+    if dtype != torch.bfloat16:
+        for kv, _ in kvs:
+            for blk in kv:
+                blk["k"], blk["v"] = blk["k"].to(dtype), blk["v"].to(dtype)
+    noise = noise.to(dtype)
     stages = stage_ref.stage_frames(stage_ref.T2V_CLEAN_STEPS)
     output = torch.zeros_like(noise)
     handoff = None
     fm = sched.FlowMatchScheduler(shift=5.0, sigma_min=0.0, extra_one_step=True)
     fm.set_timesteps(1000, training=True)
     ddmp_t = torch.tensor([[1980.0]])                  # timesteps[idx]+1000 >= 1000 for any idx (pipeline :96-107)
-    t0 = time.time()
     for si, frames in enumerate(stages):
         latents = noise[:, frames]
         if si in (2, 3):
             src = (3, 10) if si == 2 else (12, 19)
-            latents[:, 0:1] = fm.add_noise(output[:, src[0]:src[0] + 1].flatten(0, 1), renoise[frames[0]],
+            latents[:, 0:1] = fm.add_noise(output[:, src[0]:src[0] + 1].flatten(0, 1), renoise[frames[0]].to(dtype),
                                            ddmp_t.flatten(0, 1)).unflatten(0, (1, 1))
-            latents[:, -1:] = fm.add_noise(output[:, src[1]:src[1] + 1].flatten(0, 1), renoise[frames[-1]],
+            latents[:, -1:] = fm.add_noise(output[:, src[1]:src[1] + 1].flatten(0, 1), renoise[frames[-1]].to(dtype),
                                            ddmp_t.flatten(0, 1)).unflatten(0, (1, 1))
             for kv, _ in kvs:
                 for blk in kv:
@@ -169,16 +188,71 @@ def gen_chunk(steps=2):
             handoff = torch.cat([output[:, :1], latents], dim=1)
         for w in (0, 1):
             ref_forward(m, latents, 0.0, ctxs[w], kvs[w][0], kvs[w][1], frames)
-    print(f"[chunk] reference stage loop ({steps} steps/stage): {time.time() - t0:.1f}s")
+        if progress:
+            progress(si)
+    return output, handoff
+
+
+def gen_chunk50(steps=50):
+    """The REAL sampling length: 4 stages x (50 UniPC steps x 2 CFG forwards) + refresh = 408 reference forwards at
+    60x104 (casual_fps_inference.py:338-403, fm_solvers_unipc.py:655-739), plus the reference's OWN noise floor over
+    that trajectory: (i) the same run with only the K/V gather order of its self-attention changed (the reference's
+    order is `list(set(...))`, i.e. unspecified, causal_fps_model.py:219) and (ii) the same weights run in fp32."""
+    fps, model, attn, _, unipc, sched = load_reference()
+    m, sd, cfg = build_ref_model(fps, "tiny", seed=2)
+    ocfg = W.DitCfg(**cfg)
+    ctx_c, ctx_u = make_context(cfg, 21, 40), make_context(cfg, 22, 12)
+    noise = philox_normal([1, 21, 16, H, Wd], 23)
+    renoise = {f: philox_normal([1, 16, H, Wd], 100 + f) for f in (4, 9, 13, 18)}
+    tick = lambda tag: (lambda si: print(f"[chunk50] {tag}: stage {si} done at {time.time() - t0:.0f}s", flush=True))
+    t0 = time.time()
+    output, handoff = _ref_stage_loop(m, fps, unipc, sched, cfg, noise.clone(), renoise, [ctx_c, ctx_u], steps, progress=tick("ref bf16"))
+    print(f"[chunk50] reference stage loop ({steps} steps/stage): {time.time() - t0:.1f}s", flush=True)
+
+    # (i) the reference against itself with the gathered K/V rows in reverse FRAME order (softmax is permutation
+    # invariant; only the fp32 summation order inside its SDPA changes)
+    real_attention = fps.attention
+
+    def permuted_attention(q, k, v, *a, **kw):
+        n = k.shape[1] // S480
+        idx = torch.arange(n * S480).view(n, S480).flip(0).reshape(-1)
+        return real_attention(q, k[:, idx], v[:, idx], *a, **kw)
+
+    fps.attention = permuted_attention
+    t0 = time.time()
+    out_perm, hand_perm = _ref_stage_loop(m, fps, unipc, sched, cfg, noise.clone(), renoise, [ctx_c, ctx_u], steps, progress=tick("ref permuted"))
+    fps.attention = real_attention
+    print(f"[chunk50] reference, K/V frame order reversed: {time.time() - t0:.1f}s  rel_l2 vs ref: out={rel_l2(out_perm, output):.3e} "
+          f"handoff={rel_l2(hand_perm, handoff):.3e}", flush=True)
+
+    # (ii) the same weights in fp32 (model, caches, latents, attention)
+    m32 = fps.CausalFPSWanModel(model_type="t2v", dim=cfg["dim"], ffn_dim=cfg["ffn_dim"], num_heads=cfg["num_heads"],
+                                num_layers=cfg["num_layers"], text_dim=cfg["text_dim"], freq_dim=cfg["freq_dim"]).eval()
+    m32.load_state_dict({k: v.float() for k, v in sd.items()}, strict=True)
+    f32_attention = lambda q, k, v, *a, **kw: real_attention(q, k, v, *a, **dict(kw, dtype=torch.float32))
+    fps.attention, model.flash_attention = f32_attention, f32_attention
+    t0 = time.time()
+    out32, hand32 = _ref_stage_loop(m32, fps, unipc, sched, cfg, noise.clone(), renoise, [ctx_c.float(), ctx_u.float()], steps,
+                                    dtype=torch.float32, progress=tick("ref fp32"))
+    fps.attention, model.flash_attention = real_attention, attn.attention
+    print(f"[chunk50] reference in fp32: {time.time() - t0:.1f}s  rel_l2 bf16-ref vs fp32-ref: out={rel_l2(output, out32):.3e} "
+          f"handoff={rel_l2(handoff, hand32):.3e}", flush=True)
+
     t0 = time.time()
     o_out, o_hand, _ = stage_ref.run_chunk(sd, ocfg, noise, ctx_c[0], ctx_u[0], renoise, None, "t2v", 5.0, steps, 5.0)
-    print(f"[chunk] oracle stage loop: {time.time() - t0:.1f}s  rel_l2 vs ref: out={rel_l2(o_out, output):.3e} "
-          f"handoff={rel_l2(o_hand, handoff):.3e}  out rms={output.float().pow(2).mean().sqrt().item():.3f}")
+    e_or = rel_l2(o_out, output)
+    print(f"[chunk50] oracle stage loop: {time.time() - t0:.1f}s  rel_l2 vs ref: out={e_or:.3e} "
+          f"handoff={rel_l2(o_hand, handoff):.3e}  out rms={output.float().pow(2).mean().sqrt().item():.3f}", flush=True)
     torch.save(dict(out_sha=sha(output), out_strided=output[..., ::2, ::2].clone(), handoff_sha=sha(handoff),
                     handoff_strided=handoff[..., ::3, ::3].clone(),
+                    out_f32_strided=out32[..., ::2, ::2].to(torch.bfloat16).clone(),
+                    noise_floor=dict(order_out=rel_l2(out_perm, output), order_handoff=rel_l2(hand_perm, handoff),
+                                     f32_out=rel_l2(output, out32), f32_handoff=rel_l2(handoff, hand32),
+                                     perm_vs_f32_out=rel_l2(out_perm, out32), oracle_out=e_or,
+                                     oracle_handoff=rel_l2(o_hand, handoff), oracle_vs_f32_out=rel_l2(o_out, out32)),
                     meta=dict(cfg="tiny", weight_seed=2, ctx_seeds=(21, 22), n_valid=(40, 12), noise_seed=23,
                               renoise_seed_base=100, steps=steps, guidance=5.0, shift=5.0)),
-               os.path.join(HERE, "chunk_t2v_tiny.pt"))
+               os.path.join(HERE, "chunk_t2v_tiny_50.pt"))
 
 
 def gen_sched():
@@ -228,6 +302,8 @@ if __name__ == "__main__":
         gen_dit()
     if "chunk" in what:
         gen_chunk()
+    if "chunk50" in what:
+        gen_chunk50()
     if "vae" in what:
         from make_golden_vae import gen_vae
         gen_vae()

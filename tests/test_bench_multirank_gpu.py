@@ -39,3 +39,34 @@ def test_cfg_pair_with_graphed_forwards():
     assert r["value"] > 0 and r["roofline"]["achieved"] > 0
     # each rank computes ONE branch per step
     assert r["achieved_pflops_per_gpu"] > 0
+
+
+def _wavefront(gpus, extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--dist-backend", "gloo", "--model", "tiny", "--res", "tiny",
+           "--wavefront-chunks", "4", "--sampling-steps", "3"] + extra
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_measured_wavefront_two_lanes():
+    """`--wavefront-chunks`: the N > 1 line as a MEASUREMENT -- the real pipeline, the real dependency chain (chunk c + 1 starts from
+    chunk c's anchors), wall clock first noise -> last latent; two ranks on one GPU over gloo (functional)."""
+    r = _wavefront(2, [])
+    assert r["n_gpus"] == 2 and r["chunks"] == 4 and r["lanes"] == 2 and "measured wavefront" in r["config"]["parallelism"]
+    assert abs(r["value"] - 21.0 * 4 / r["wall_s"]) < 1e-9 and r["value_modelled"] > 0
+    assert len(r["chunk_s"]) == 4 and len(r["stagger_s"]) == 3 and all(s > 0 for s in r["stagger_s"])
+    # chunk c + 1 cannot start before chunk c's anchor stage is done (the dependency is real)
+    assert all(st >= a - 0.05 for st, a in zip(r["stagger_s"], r["anchor_done_after_s"]))
+    assert set(r["rank_busy_fraction"]) == {"0", "1"} and all(0 < v <= 1.0 for v in r["rank_busy_fraction"].values())
+    assert set(r["handoff_latency_s"]) == {"1", "2", "3"} and all(0 <= v < 30 for v in r["handoff_latency_s"].values())
+    assert "not_the_metric" in r and "functional_only" in r          # 3 sampling steps, shared GPU
+
+
+def test_measured_wavefront_one_rank_is_the_sequential_chain():
+    r = _wavefront(1, [])
+    assert r["n_gpus"] == 1 and r["lanes"] == 1 and "sequential chain" in r["config"]["parallelism"]
+    assert sum(r["chunk_s"]) <= r["wall_s"] * 1.001 and r["rank_busy_fraction"]["0"] > 0.5

@@ -167,3 +167,36 @@ def test_build_then_smoke_in_one_process():
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "[smoke]" in r.stdout
+
+
+@pytest.mark.parametrize("n_valid", [0, 1, 37, 63, 64, 65, 448, 510, 511, 512])
+def test_cross_attention_padded_tail_collapse(n_valid):
+    """The zero-padded tail of the text context is ONE repeated K / V row after the text embedding (utils/wan_wrapper.py:46-47 zeroes
+    it, causal_fps_model.py:780 / model.py:189 attend over it unmasked): the forward attends over n_valid + 1 keys with the last one
+    weighted 512 - n_valid times (api.hip).  Same forward through a cross cache the engine does NOT know to collapse (a copy at
+    another address: all 512 keys) -- equal up to the rounding of one P entry; n_valid >= 511 leaves nothing to collapse."""
+    from mmpl_amd.dit import DitEngine
+    from mmpl_amd.synthetic import WAN_CONFIGS, dit_state_dict, philox_normal
+    cfg = WAN_CONFIGS["tiny"]
+    eng = DitEngine(cfg, 16, 24, "cuda:0")
+    eng.load_state_dict(dit_state_dict(cfg, seed=3))
+    ctx = philox_normal([512, cfg["text_dim"]], 40 + n_valid)
+    ctx[n_valid:] = 0
+    ck, cv = eng.precompute_context(ctx.cuda())
+    ck2, cv2 = ck.clone(), cv.clone()
+    # the padded K / V rows really are one row (what the collapse relies on), in every layer
+    if n_valid < 511:
+        assert (ck[:, n_valid:] == ck[:, 511:]).all() and (cv[:, n_valid:] == cv[:, 511:]).all()
+    frames = [0, 1]
+    x = philox_normal([2, 16, 16, 24], 7).cuda()
+    t = torch.full([2], 700.0, dtype=torch.float32).cuda()
+    outs = []
+    for k_, v_ in ((ck, cv), (ck2, cv2)):
+        kc, vc = eng.new_kv_cache(15)
+        outs.append(eng.forward(x, t, frames, [0, 1], [0, 1], kc, vc, k_, v_).clone())
+    torch.cuda.synchronize()
+    e = rel_l2(outs[0], outs[1])
+    print(f"n_valid {n_valid}: rel_l2(collapsed, all 512 keys) = {e:.3e}")
+    assert torch.isfinite(outs[0].float()).all() and e < 2e-3
+    if n_valid >= 511:
+        assert torch.equal(outs[0], outs[1])

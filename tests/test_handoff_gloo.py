@@ -79,3 +79,60 @@ def test_stitch_chunks_drops_five_overlap_frames():
     v = [torch.arange(81).view(1, 81, 1).float() + 100 * i for i in range(3)]
     s = stitch_chunks(v)
     assert s.shape[1] == 81 + 76 + 76 and s[0, 81, 0] == 105 and s[0, 80, 0] == 80
+
+
+def _hs_worker(rank, world, port, out_path):
+    """5 chunks over 2 ranks with unequal chunk lengths: rank 0's chunks take long AFTER their sink (so its consumer announces
+    ready while rank 0 still "computes" -> issued by a poll), rank 1's sinks come while rank 0 is still busy (deferred)."""
+    import datetime
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    ho = ChunkHandoff(SHAPE, "cpu")
+    ev = []
+    issue = ho._issue
+
+    def spy(chunk, hdr, payload):
+        # the invariant the handshake exists for: a send is only ever issued against an announced consumer
+        req, _ = ho._ready_req[chunk + 1]
+        ev.append(("issue", chunk, bool(req.is_completed())))
+        issue(chunk, hdr, payload)
+    ho._issue = spy
+
+    def make_chunk(c, initial, sink):
+        base = torch.full(SHAPE, float(c + 1), dtype=torch.bfloat16)
+        if initial is not None:
+            base = base + initial.float().mean().to(torch.bfloat16)
+        time.sleep(0.2)                      # "anchor stage"
+        sink(base)
+        ev.append(("sink", c, len(ho._deferred)))
+        for _ in range(6 if rank == 0 else 1):     # "in-fill stages", a poll at every stage boundary
+            time.sleep(0.25)
+            ho.poll()
+        return base[:, :2].clone()
+
+    res = run_chunk_wavefront(make_chunk, 5, ho, to_initial=lambda t: t[:, :2])
+    torch.save({"ev": ev, "res": res, "stats": ho.stats}, f"{out_path}.{rank}")
+    dist.destroy_process_group()
+
+
+def test_ready_handshake_defers_sends_until_the_consumer_announced(tmp_path):
+    out = str(tmp_path / "hs")
+    mp.spawn(_hs_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = (torch.load(f"{out}.{r}") for r in range(2))
+    assert [float(t.float().mean()) for t in r0["res"]] == [1.0, 3.0, 6.0, 10.0, 15.0]      # same chain as without the handshake
+    for r in (r0, r1):
+        issues = [e for e in r["ev"] if e[0] == "issue"]
+        assert issues and all(e[2] for e in issues), issues            # never issued before the consumer's announcement had arrived
+    # rank 1's chunks end their anchor stage while rank 0 is still inside its long chunk: deferred at the sink
+    assert any(e[0] == "sink" and e[2] == 1 for e in r1["ev"]), r1["ev"]
+    # rank 0 -> rank 1: the consumer is idle and announces early -- issued at the sink or by one of the polls of the long in-fill
+    # part, in any case before rank 0's next chunk (not only by the blocking drain at the end of the wavefront)
+    kinds = [(e[0], e[1]) for e in r0["ev"]]
+    assert kinds.index(("issue", 0)) < kinds.index(("sink", 2)) and kinds.index(("issue", 2)) < kinds.index(("sink", 4))
+    # stamps of every hand-off on the consumer side: sink (producer clock, same host) <= recv done, ready announced before recv done
+    for r, chunks in ((r0, (2, 4)), (r1, (1, 3))):
+        for c in chunks:
+            st = r["stats"][c]
+            assert st["t_ready"] <= st["t_recv_done"] and st["t_sink"] <= st["t_recv_done"] + 1e-3, (c, st)

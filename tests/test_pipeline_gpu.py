@@ -17,13 +17,13 @@ LAT = (16, 24)
 TRAJ_TOL = 1.5e-2
 
 
-def _setup(mode="t2v", steps=2, with_vae=False):
+def _setup(mode="t2v", steps=2, with_vae=False, lat=LAT):
     from mmpl_amd.geometry import Geometry
     from mmpl_amd.pipeline import CausalFPSInferencePipeline
     from mmpl_amd.synthetic import WAN_CONFIGS, dit_state_dict, philox_normal, vae_state_dict
     from mmpl_amd.wan_wrapper import WanFPSWrapper, WanTextEncoder, WanVAEWrapper
     cfg = WAN_CONFIGS["tiny"]
-    geo = Geometry(*LAT)
+    geo = Geometry(*lat)
     sd = dit_state_dict(cfg, seed=2)
     gen = WanFPSWrapper(is_causal=True, timestep_shift=5.0, model_config=cfg, geometry=geo, device="cuda:0")
     gen.load_state_dict({"model." + k: v for k, v in sd.items()})          # MMPL checkpoint key style
