@@ -86,6 +86,7 @@ def parse():
                          "wall clock first noise -> last latent: value = 21 C / wall (SURVEY 8d), per-rank busy fraction, stagger, hand-off latency")
     ap.add_argument("--sampling-steps", type=int, default=50, help="UniPC steps per stage of --wavefront-chunks (50 = the reference's; fewer = a "
                          "shorter functional run whose value is NOT the metric and is labelled so)")
+    ap.add_argument("--heavy-tail-gain", type=float, default=8.0, help="QK-norm gain multiplier of --heavy-tail (8 = the test's; logit std ~ gain^2 nats)")
     ap.add_argument("--heavy-tail", action="store_true",
                     help="NOT the headline: the statistics real checkpoints have and unit-variance synthetic weights do not (QK-norm gains x8, "
                          "six massive-activation channels -- the weights of tests/test_fullsize_gpu.py's heavy-tail case): how much of the "
@@ -394,7 +395,7 @@ def main():
         if args.heavy_tail:
             for l in range(cfg["num_layers"]):
                 for k in ("self_attn.norm_q.weight", "self_attn.norm_k.weight"):
-                    sd[f"blocks.{l}.{k}"] = (sd[f"blocks.{l}.{k}"].float() * 8.0).to(torch.bfloat16)
+                    sd[f"blocks.{l}.{k}"] = (sd[f"blocks.{l}.{k}"].float() * args.heavy_tail_gain).to(torch.bfloat16)
             b = sd["patch_embedding.bias"].float()
             cols = [c % cfg["dim"] for c in (7, 300, 1111, 2049, 3333, 5000)]
             b[cols] = torch.tensor([60.0, -60.0, 45.0, -45.0, 60.0, -50.0], device=b.device)
@@ -661,7 +662,7 @@ def main():
             # overflowed / underflowed and were redone by the GENERAL pass (attn_w64.hip); caches hold K / V written by real forwards
             "attn_blocks": attn_blocks, "attn_blocks_redone": attn_redone,
             "attn_blocks_redone_fraction": (attn_redone / attn_blocks) if attn_blocks else None,
-            **({"weights": "heavy-tailed synthetic (QK-norm gains x8, six massive-activation channels): NOT the headline workload"}
+            **({"weights": f"heavy-tailed synthetic (QK-norm gains x{args.heavy_tail_gain:g}, six massive-activation channels): NOT the headline workload"}
                if args.heavy_tail else {}),
         }
         if eager_step_s is not None:

@@ -21,13 +21,18 @@
 // accumulator is finished >= 2 MFMAs before the VALU touches it and each P >= 2 gaps before its MFMA.
 //
 // Softmax without a row max on the common path.  Q is prescaled, so S is in log2 units and p = exp2(S - m_ref) against a per-row
-// reference m_ref.  FAST pass: m_ref = 0 for every row (p = exp2(S): one v_exp, one add and half a cvt_pk per score, and NOTHING
-// per tile that could branch).  Every p is >= 0, so the row sums only grow: one look at them after the last tile tells whether
-// any exponential overflowed or all of them underflowed (2^-40 <= l <= 2^100 is required, NaN fails).  If any row of the block
-// fails, the whole block is redone by the GENERAL pass: p = exp2(S - m_ref) (one more VALU per score), a tile is accepted when
-// every lane's partial row sum is <= 2^30, otherwise it is redone on a slow path (exact row max, m_ref = max(m_ref, max), O and
-// l rescaled through v_accvgpr moves, p recomputed).  So the result is the exact softmax up to rounding for any input (tests:
-// spiked scores far beyond both bounds); inputs that a FAST pass cannot hold cost that block two passes.
+// reference m_ref.  FAST pass: m_ref is FIXED for the whole pass and costs nothing in the loop -- it is the C operand of each score
+// tile's first MFMA (the register tile that also carries the ragged-tile mask holds -m_ref instead of 0), so S arrives already
+// shifted: one v_exp, one add and half a cvt_pk per score, and NOTHING per tile that could branch.  m_ref = 64 + the largest score of
+// the block's first KV tile (32 extra MFMAs per 256-row block before the pipeline starts; a lane's two query rows share one value).
+// Every p is >= 0, so the row sums only grow: one look at them after the last tile tells whether any exponential overflowed
+// (2^-100 <= l <= 2^100 is required, NaN fails) -- i.e. whether some later score beat the first tile's maximum by more than ~150
+// (log2 units; ~100 nats).  Round 3 used m_ref = 0, which holds for unit-gain synthetic weights only: with QK-norm gains x8 91 % of
+// the blocks failed it and ran twice (profiles/r04a_bench_14B_720p_heavy_tail_before_row_reference.json).  If any row of the block
+// fails, the whole block is redone by the GENERAL pass: p = exp2(S - m_ref) with a RUNNING reference (one more VALU per score), a
+// tile is accepted when every lane's partial row sum is <= 2^30, otherwise it is redone on a slow path (exact row max,
+// m_ref = max(m_ref, max), O and l rescaled through v_accvgpr moves, p recomputed).  So the result is the exact softmax up to rounding
+// for any input (tests: spiked scores far beyond both bounds); inputs that a FAST pass cannot hold cost that block two passes.
 //
 // Nothing in the steady loop branches except its back edge.  Everything that happens once per page -- the K / V cursors
 // switching buffer descriptors, the ragged last tile's mask, a cursor parking on the block's last tile -- is decided between
@@ -45,7 +50,8 @@ namespace {
 constexpr int QB = 256, KVB = 64, TILE = KVB * 256, RING = 4;         // K ring [0, 64 KiB), V ring [64 KiB, 128 KiB)
 constexpr int W64_SMEM = 2 * RING * TILE + 64;     // + the block's redo flag
 constexpr float BOUND_GEN = 1073741824.f;                              // 2^30: a GENERAL tile's partial row sums
-constexpr float FAST_L_MIN = 9.094947e-13f, FAST_L_MAX = 1.2676506e30f;       // 2^-40, 2^100: a FAST pass's final row sums
+constexpr float FAST_L_MIN = 7.888609e-31f, FAST_L_MAX = 1.2676506e30f;       // 2^-100, 2^100: a FAST pass's final row sums
+constexpr float FAST_REF_OFFSET = 64.f;       // FAST pass: m_ref = (largest score of the block's first KV tile) + this
 
 using w64::sfor;
 #define ALL_AGPRS MMPL_ALL_AGPRS
@@ -85,6 +91,7 @@ struct Ctx {
   u32x4 P[2][4];         // [query block][16-row kv step]: 8 bf16 = B operand of O^T += V^T.P^T
   bf16x8 kf[16];         // K fragments of one tile: i = 2*chunk + half
   float l[2], mref[2];   // running row sum (this lane's 32 kv columns of every tile) and reference (log2 units)
+  float mbase;           // what an unmasked entry of the C-operand tile M holds: -m_ref in a FAST pass, 0 in a GENERAL one
   float la[2], lb[2];    // the tile's partial sums (even / odd register of each pair)
   float t[2][2][2];      // exp results in flight: [stream][pair parity][element]
   uint32_t dko[4], dvo[4];   // per-piece LDS-DMA source offsets within a tile (constant)
@@ -230,7 +237,7 @@ struct Ctx {
     // register r of half h holds kv row 32 h + 8 (r >> 2) + (r & 3) + 4 hi: one compare of 4 hi against a scalar per register
     // (written as asm so that the 32 compares do not all stay live in SGPR pairs at once)
     const int hi4 = 4 * hi;
-    const float ninf = -INFINITY, zero = 0.f;
+    const float ninf = -INFINITY, zero = mbase;
     Ctx* self = this;
     sfor<32>([self, hi4, ninf, zero, valid](auto ii) {
       constexpr int i = decltype(ii)::value, h = i >> 4, r = i & 15;
@@ -243,7 +250,7 @@ struct Ctx {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) MREG(h, r) = 0.f;
+      for (int r = 0; r < 16; ++r) MREG(h, r) = mbase;
     masked = 0;
   }
   MMPL_DEV int plan(int j) {
@@ -344,6 +351,12 @@ struct Ctx {
     asm volatile("s_nop 1" ::: "memory");             // VALU-written P -> MFMA operand
     return lt;
   }
+  MMPL_DEV float score_max() {                           // largest of this lane's 64 scores (both query blocks, both kv halves)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(fmaxf(mx, fmaxf(SREG(0, 0, r), SREG(0, 1, r))), fmaxf(SREG(1, 0, r), SREG(1, 1, r)));
+    return mx;
+  }
   template <int MODE, int X> MMPL_DEV void finish() {
     if constexpr (MODE == 0 || (W64_ABL & (2 | 4 | 32 | 64 | 128))) return;     // FAST: la / lb run on; timing ablations: no slow path
     float lt = la[X] + lb[X];
@@ -366,6 +379,7 @@ template <int MODE> MMPL_DEV void w64_pass(Ctx& k) {
   k.l[0] = k.l[1] = 0.f;
   k.la[0] = k.la[1] = k.lb[0] = k.lb[1] = 0.f;
   k.mref[0] = k.mref[1] = 0.f;
+  k.mbase = 0.f;
   k.first[0] = k.first[1] = 1;
   k.clear_mask();
   k.kslot = k.wave_slot; k.vslot = RING * TILE + k.wave_slot;
@@ -392,6 +406,22 @@ template <int MODE> MMPL_DEV void w64_pass(Ctx& k) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   k.plan(0);
+#if !W64_MOCK16
+  if constexpr (MODE == 0 && W64_ABL == 0) {
+    // FAST pass reference (header): the scores of KV tile 0 for both query blocks, their largest per lane (= two query rows) + offset
+    // becomes m_ref; it enters every later score through the C operand of the tile's first MFMA, so the pipeline below is untouched.
+    sfor<16>([&k](auto gi) { k.template mfma_qk<0, decltype(gi)::value>(); });
+    sfor<16>([&k](auto gi) { k.template mfma_qk<1, decltype(gi)::value>(); });
+    k.mfma_write_pad();
+    float mx = k.score_max();
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fminf(fmaxf(mx, -1e30f), 1e30f);              // (a NaN / inf score: the end-of-pass check fails and GENERAL takes over)
+    k.mref[0] = k.mref[1] = mx + FAST_REF_OFFSET;
+    k.mbase = -(mx + FAST_REF_OFFSET);
+    k.masked = 1;                                      // make plan() rewrite the C-operand tile (mask of tile 0 included) on the new base
+    k.plan(0);
+  }
+#endif
   w64_phase_a<MODE, true, false, true, false>(k);
   w64_phase_b<MODE, true, false, true, false>(k);
   [[maybe_unused]] unsigned long long tick0 = 0;

@@ -174,7 +174,9 @@ def test_cross_attention_padded_tail_collapse(n_valid):
     """The zero-padded tail of the text context is ONE repeated K / V row after the text embedding (utils/wan_wrapper.py:46-47 zeroes
     it, causal_fps_model.py:780 / model.py:189 attend over it unmasked): the forward attends over n_valid + 1 keys with the last one
     weighted 512 - n_valid times (api.hip).  Same forward through a cross cache the engine does NOT know to collapse (a copy at
-    another address: all 512 keys) -- equal up to the rounding of one P entry; n_valid >= 511 leaves nothing to collapse."""
+    another address: all 512 keys) -- equal up to the bf16 rounding of the padded key's P entry (bf16(c * p) vs c * bf16(p): up to
+    2 * 2^-9 of that key's share of the output, which is nearly all of it when n_valid is 0 or 1); n_valid >= 511 leaves nothing
+    to collapse."""
     from mmpl_amd.dit import DitEngine
     from mmpl_amd.synthetic import WAN_CONFIGS, dit_state_dict, philox_normal
     cfg = WAN_CONFIGS["tiny"]
@@ -197,6 +199,6 @@ def test_cross_attention_padded_tail_collapse(n_valid):
     torch.cuda.synchronize()
     e = rel_l2(outs[0], outs[1])
     print(f"n_valid {n_valid}: rel_l2(collapsed, all 512 keys) = {e:.3e}")
-    assert torch.isfinite(outs[0].float()).all() and e < 2e-3
+    assert torch.isfinite(outs[0].float()).all() and e < 4e-3
     if n_valid >= 511:
         assert torch.equal(outs[0], outs[1])
