@@ -470,6 +470,7 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
         // (WanI2VCrossAttention.forward, model.py:254-263).  The scratch K pages are free here: they hold the image output.
         a.o = w.ksc;
         a.page_rows = h->n_img;
+        a.last_row_copies = 0;                    // (the text stream's weighted padded key does not apply to the image tokens)
         a.k_pages[0] = h->img_k + (size_t)l * h->n_img * d;
         a.v_pages[0] = h->img_v + (size_t)l * h->n_img * d;
         ProfScope ps2(K_ATTN_CROSS, 4.0 * Lq * (double)h->n_img * d, s);

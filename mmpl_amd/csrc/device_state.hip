@@ -92,7 +92,8 @@ const MmplRuntimeConfig& mmpl_config() {
     c.gemm_no_splitk = flag("MMPL_GEMM_NO_SPLITK");
     c.gemm_group = num("MMPL_GEMM_GROUP", 0);
     c.gemm_pf = num("MMPL_GEMM_PF", 2);
-    c.vae_no_halo = flag("MMPL_VAE_NO_HALO");
+    c.gemm_v8 = num("MMPL_GEMM_V8", -1);
+    c.vae_no_halo = flag("MMPL_VAE_NO_HALO"); c.vae_no_fuse_norm = flag("MMPL_VAE_NO_FUSE_NORM");
     return c;
   }();
   return cfg;

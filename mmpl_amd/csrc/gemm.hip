@@ -12,9 +12,11 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "w64_util.h"
 #include "mmpl_config.h"
 
 namespace {
+using w64::sfor;
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
@@ -748,11 +750,228 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+#ifndef GEMM8_ABL
+#define GEMM8_ABL 0         // dev ablations of the v8 loop (results are garbage): 1 no LDS-DMA, 4 no fragment reads, 8 no barriers / waits
+#endif
+// ---------------------------------------------------------------------------------------------------------------
+// v8 "w128": the same 256x256x64 block tile, 2-stage LDS-DMA ring, LDS image, tile order / tickets and epilogues as v6, but FOUR waves,
+// one per SIMD, each a 128 x 128 sub-tile = 8 x 8 fragments of v_mfma_f32_16x16x32_bf16 whose 256 fp32 accumulators are the
+// accumulator file (a[0:255], named literally; acc(i, j) = a[4 (8 i + j) ..+3]).  Per k-tile a wave issues 128 MFMAs and reads 32
+// fragments (16 activation + 16 weight) -- 0.25 ds_read_b128 per MFMA where v6's 128 x 64 wave tile needs 0.375: on this power-limited
+// chip LDS bytes are energy, and the wide block GEMMs (qkv, ffn0: half of a forward's GEMM FLOPs) are where the vendor library's
+// kernel of this geometry was 9-14 % ahead of v6 (profiles/r03b_gemm6_diag.log).  Round 3's first cut of this geometry kept a 4-deep
+// ring of 32-wide stages and lost to v6; this one holds the WHOLE current k-tile in registers (2 x 16 fragments = 128 VGPRs):
+//   phase 1 of tile t:  64 MFMAs on the first 32-wide half (fragments already in registers) | the 16 fragments of the second half are
+//                       read from stage t & 1; once every wave has them (lgkmcnt(0) + barrier) that stage is dead, and the LDS-DMA of
+//                       tile t+2 goes straight into it
+//   phase 2 of tile t:  64 MFMAs on the second half | the rest of tile t+2's 16 DMA pieces; vmcnt(16) + barrier = tile t+1 has landed
+//                       for everybody; its first-half fragments are read from the other stage
+// so two tiles are in flight with two stages, every DMA piece has > 128 MFMA times (~1 us) to land, and nothing but MFMAs, 32 reads,
+// 16 DMA pieces and 2 barriers is issued per k-tile.  Same MFMA operand order and per-accumulator k order as v6: bit-identical results.
+struct G8 {
+  bf16x8 af[2][8], wf[2][8];      // [32-wide half of the k-tile][fragment]: activations (B operand), weights (A operand)
+  uint32_t ra[2][2], rw[2][2];    // fragment-0 LDS read address [stage][half]; fragment i at + 2048 i
+  uint32_t a_vo[8], w_vo[8];      // per-piece LDS-DMA source byte offsets (constant over k)
+  const bf16_t* a_k; const bf16_t* w_k;   // operand base of the next k-tile to fetch
+  uint32_t dst0;                  // LDS address of this wave's piece 0 of stage 0's activation half (piece q at + 4096 q)
+
+  template <int KS, int I, int J> MMPL_DEV void mfma() {
+    constexpr int c = 4 * (8 * I + J);
+    asm volatile("v_mfma_f32_16x16x32_bf16 a[%c0:%c1], %2, %3, a[%c0:%c1]" ::"i"(c), "i"(c + 3), "v"(wf[KS][J]), "v"(af[KS][I]));
+  }
+  template <int S, int KS, int R> MMPL_DEV void lds() {      // fragment R of half KS of the tile in stage S: weights first, then activations
+    if constexpr (GEMM8_ABL & 4) return;
+    if constexpr (R < 8) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(wf[KS][R]) : "v"(rw[S][KS]), "i"(2048 * R));
+    else asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(af[KS][R - 8]) : "v"(ra[S][KS]), "i"(2048 * (R - 8)));
+  }
+  template <int S, int Q> MMPL_DEV void dma() {              // piece Q of the next tile into stage S: Q < 8 activation rows, else weight rows
+    if constexpr (GEMM8_ABL & 1) return;
+    constexpr int q = Q & 7;
+    const uint32_t m = dst0 + S * STAGE4 + (Q < 8 ? 0 : A4_BYTES) + 4096 * q;
+    if constexpr (Q < 8) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(a_vo[q]), "s"(a_k), "s"(m) : "memory");
+    else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(w_vo[q]), "s"(w_k), "s"(m) : "memory");
+  }
+};
+
+// gap placement of one k-tile (dev sweep: -DGEMM8_...)
+#ifndef GEMM8_BAR1
+#define GEMM8_BAR1 36        // phase 1: lgkmcnt(0) + barrier (the 16 second-half reads sit in gaps 0, 2, .. 30)
+#endif
+#ifndef GEMM8_DMAS
+#define GEMM8_DMAS 3         // gaps between DMA pieces (never back to back: the four waves run in step and the CU has one address path)
+#endif
+#ifndef GEMM8_BAR2
+#define GEMM8_BAR2 30        // phase 2: vmcnt + barrier, then the next tile's first-half reads in gaps BAR2 + 2, + 4, ..
+#endif
+// S: ring stage of this tile; ISSUE: tile t+2 exists (fetch it into stage S); NEXT: tile t+1 exists (read its first half)
+template <int S, bool ISSUE, bool NEXT> MMPL_DEV void gemm8_tile(G8& k) {
+  constexpr int D1 = GEMM8_BAR1 + 2;                                   // first DMA gap of phase 1
+  constexpr int N1 = (64 - D1 + GEMM8_DMAS - 1) / GEMM8_DMAS;          // pieces issued in phase 1
+  static_assert(N1 >= 0 && N1 <= 16 && (16 - N1) * GEMM8_DMAS < GEMM8_BAR2 && GEMM8_BAR2 + 2 + 2 * 15 < 64, "placement");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // this tile's first-half fragments
+  sfor<64>([&k](auto gi) {
+    constexpr int g = decltype(gi)::value;
+    k.template mfma<0, g / 8, g % 8>();
+    if constexpr ((g & 1) == 0 && g < 32) k.template lds<S, 1, g / 2>();
+    if constexpr (g == GEMM8_BAR1 && !(GEMM8_ABL & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (ISSUE && g >= D1 && (g - D1) % GEMM8_DMAS == 0) k.template dma<S, (g - D1) / GEMM8_DMAS>();
+  });
+  sfor<64>([&k](auto gi) {
+    constexpr int g = decltype(gi)::value;
+    k.template mfma<1, g / 8, g % 8>();
+    if constexpr (ISSUE && g % GEMM8_DMAS == 0 && N1 + g / GEMM8_DMAS < 16) k.template dma<S, N1 + g / GEMM8_DMAS>();
+    if constexpr (NEXT && g == GEMM8_BAR2 && !(GEMM8_ABL & 8)) {
+      if constexpr (ISSUE) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if constexpr (NEXT && g > GEMM8_BAR2 && ((g - GEMM8_BAR2) & 1) == 0 && (g - GEMM8_BAR2) / 2 <= 16) k.template lds<S ^ 1, 0, (g - GEMM8_BAR2) / 2 - 1>();
+  });
+  if constexpr (ISSUE) { k.a_k += BK4; k.w_k += BK4; }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_v8_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_ticket;
+  const int tiles_m = (g.M + BM3 - 1) / BM3, tiles_n = (g.N + BN3 - 1) / BN3;
+  const int nwg = tiles_m * tiles_n;
+  // tile order, tickets and the split between the main launch and the split-K tail launch: exactly v6's (see gemm_bf16_v6_kernel)
+  const bool persistent = g.tile_counter != nullptr;
+  const int my_xcd = blockIdx.x & 7;
+  const int GROUP = g.group;
+  const int per_group = GROUP * tiles_n;
+  const int full_groups = tiles_m / GROUP;
+  const int rounds = g.sync_sweeps ? full_groups >> 3 : 0;
+  const int dealt = rounds * per_group;
+  const int left = nwg - 8 * dealt;
+  const int lq = left >> 3, lr = left & 7;
+  const int chunk_all = dealt + lq + (my_xcd < lr ? 1 : 0);
+  const int chunk = g.splitk_s > 1 ? chunk_all - chunk_all % g.splitk_per : chunk_all;
+  const int blocks_x = (int)(gridDim.x >> 3) + (my_xcd < (int)(gridDim.x & 7) ? 1 : 0);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 15, fchunk = lane >> 4;
+  asm volatile("s_nop 0" ::: MMPL_ALL_AGPRS);
+
+  G8 k;
+  {
+    const uint32_t ring = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)smem);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        k.ra[s][ks] = ring + s * STAGE4 + (swz64(128 * wm + frow, fchunk) ^ (ks << 6));
+        k.rw[s][ks] = ring + s * STAGE4 + A4_BYTES + (swz64(128 * wn + frow, fchunk) ^ (ks << 6));
+      }
+    k.dst0 = ring + 1024 * wave;
+  }
+  const int prow = lane >> 3, lc = ((lane & 7) ^ (prow & 7)) << 3;     // row within a piece, swizzled source chunk (elements)
+  const int nt = g.K / BK4;
+
+  for (;;) {
+    int idx = blockIdx.x >> 3;
+    if (persistent) {
+      if (threadIdx.x == 0) s_ticket = atomicAdd(g.tile_counter + my_xcd, 1);
+      __syncthreads();
+      const int ticket = s_ticket;
+      if (ticket >= chunk) {
+        if (ticket == chunk + blocks_x - 1 && threadIdx.x == 0) g.tile_counter[my_xcd] = 0;
+        return;
+      }
+      idx = ticket;
+    } else if (idx >= chunk) {
+      return;
+    }
+    int bid;
+    if (idx < dealt) bid = ((idx / per_group) * 8 + my_xcd) * per_group + idx % per_group;
+    else bid = 8 * dealt + (my_xcd < lr ? my_xcd * (lq + 1) : lr * (lq + 1) + (my_xcd - lr) * lq) + (idx - dealt);
+    const int gid = bid / per_group;
+    const int first_m = gid * GROUP;
+    const int gsz = min(tiles_m - first_m, GROUP);
+    const int tm = first_m + (bid % per_group) % gsz;
+    const int tn = (bid % per_group) / gsz;
+    const int m0 = tm * BM3, n0 = tn * BN3;
+
+    // piece p = 4 q + wave of an operand's 32: rows 8 p .. 8 p + 7 (clamped at the matrix edge; the epilogue never stores those rows)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int p = 4 * q + wave;
+      k.a_vo[q] = (uint32_t)(min(m0 + 8 * p + prow, g.M - 1) * g.lda + lc) * 2u;
+      k.w_vo[q] = (uint32_t)(min(n0 + 8 * p + prow, g.N - 1) * g.ldw + lc) * 2u;
+    }
+    k.a_k = g.A; k.w_k = g.W;
+    sfor<256>([](auto ii) { asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(decltype(ii)::value)); });
+
+    // ---- prologue: tiles 0 and 1 into the two stages, tile 0's first-half fragments into registers
+    sfor<16>([&k](auto q) { k.template dma<0, decltype(q)::value>(); });
+    k.a_k += BK4; k.w_k += BK4;
+    if (nt > 1) {
+      sfor<16>([&k](auto q) { k.template dma<1, decltype(q)::value>(); });
+      k.a_k += BK4; k.w_k += BK4;
+      asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    sfor<16>([&k](auto r) { k.template lds<0, 0, decltype(r)::value>(); });
+
+    int t = 0;
+#pragma unroll 1
+    for (; t + 3 < nt; t += 2) {
+      gemm8_tile<0, true, true>(k);
+      gemm8_tile<1, true, true>(k);
+    }
+    if (nt - t == 3) {
+      gemm8_tile<0, true, true>(k);
+      gemm8_tile<1, false, true>(k);
+      gemm8_tile<0, false, false>(k);
+    } else if (nt - t == 2) {
+      gemm8_tile<0, false, true>(k);
+      gemm8_tile<1, false, false>(k);
+    } else {
+      gemm8_tile<0, false, false>(k);
+    }
+    // every wave is past the last tile's phase-1 barrier: nobody reads the ring any more, the epilogue stages through it.
+    // (the MFMA results need their passes before a VALU instruction may read the accumulator file)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+
+    // ---- epilogue: v6's, on the two 128 x 64 halves of the wave's sub-tile.  Its lane-dependent addresses are derived from an
+    // OPAQUE copy of the lane id defined here: otherwise hipcc hoists them above the k loop and, short of VGPRs there, parks them
+    // in accumulator registers -- which this kernel owns by name (tests/test_isa_audit.py fails on any compiler access to a[..]).
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int frow_e = lane_e & 15, fchunk_e = lane_e >> 4;
+    sfor<2>([&](auto nhi) {
+      constexpr int nh = decltype(nhi)::value;
+      f32x4 acc[2][4][4];
+      sfor<128>([&acc](auto ii) {
+        constexpr int x = decltype(ii)::value, i8 = x >> 4, j = (x >> 2) & 3, r = x & 3;
+        float v;
+        asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "i"(4 * (8 * i8 + 4 * nh + j) + r));
+        acc[i8 >> 2][i8 & 3][j][r] = v;
+      });
+      const int mw = m0 + 128 * wm, nw = n0 + 128 * wn + 64 * nh;
+      if (EPI != EPI_F32_SCALE && g.staged_epilogue) {
+        gemm_epilogue_staged<EPI>(g, acc, smem + wave * 32768 + nh * 16384, mw, nw, lane_e);
+      } else {
+        gemm_epilogue<EPI>(g, acc[0], mw, nw, frow_e, fchunk_e);
+        gemm_epilogue<EPI>(g, acc[1], mw + 64, nw, frow_e, fchunk_e);
+      }
+    });
+    if (!persistent) return;
+    __syncthreads();                 // the ring (and s_ticket) are free again
+  }
+}
+
 template <int EPI>
 hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
   constexpr int smem = 2 * STAGE4 + 1024;        // ring + the L2 prefetch's dump area
   if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v6_kernel<EPI>), smem); e != hipSuccess) return e;
   if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v6_kernel<EPI, true>), smem); e != hipSuccess) return e;
+  if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v8_kernel<EPI>), 2 * STAGE4); e != hipSuccess) return e;
+  // main-launch kernel: v8 (one wave per SIMD, 128 x 128 per wave) or v6 (two, 128 x 64).  MMPL_GEMM_V8 = 1 / 0 forces it.
+  const int env_v8 = mmpl_config().gemm_v8;
+  const bool use_v8 = env_v8 >= 0 ? env_v8 != 0 : false;
   const int tiles = ((g.M + BM3 - 1) / BM3) * ((g.N + BN3 - 1) / BN3);
   GemmArgs g2 = g;
   const MmplRuntimeConfig& rc = mmpl_config();
@@ -804,14 +1023,18 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
     sp = sp > 4 ? 4 : sp;
     if (sp >= 2 && (size_t)8 * tb * sp * (BM3 * BN3 * sizeof(float)) <= mmpl_gemm_splitk_ws_bytes()) {
       g2.splitk_s = sp; g2.splitk_tb = tb;
-      if (main_tiles > 0) hipLaunchKernelGGL(gemm_bf16_v6_kernel<EPI>, dim3(main_tiles < n_cu ? main_tiles : n_cu), dim3(512), smem, s, g2);
+      if (main_tiles > 0) {
+        if (use_v8) hipLaunchKernelGGL(gemm_bf16_v8_kernel<EPI>, dim3(main_tiles < n_cu ? main_tiles : n_cu), dim3(256), 2 * STAGE4, s, g2);
+        else hipLaunchKernelGGL(gemm_bf16_v6_kernel<EPI>, dim3(main_tiles < n_cu ? main_tiles : n_cu), dim3(512), smem, s, g2);
+      }
       hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, true>), dim3(8 * tb * sp), dim3(512), smem, s, g2);
       return hipGetLastError();
     }
   }
   const int blocks = g2.tile_counter && tiles > n_cu ? n_cu : tiles;
   if (blocks == tiles) g2.tile_counter = nullptr;             // one round or less: nothing to balance
-  hipLaunchKernelGGL(gemm_bf16_v6_kernel<EPI>, dim3(blocks), dim3(512), smem, s, g2);
+  if (use_v8) hipLaunchKernelGGL(gemm_bf16_v8_kernel<EPI>, dim3(blocks), dim3(256), 2 * STAGE4, s, g2);
+  else hipLaunchKernelGGL(gemm_bf16_v6_kernel<EPI>, dim3(blocks), dim3(512), smem, s, g2);
   return hipGetLastError();
 }
 

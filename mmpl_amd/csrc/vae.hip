@@ -10,6 +10,7 @@
 
 #include "../../include/mmpl_hip.h"
 #include "kernels.h"
+#include "mmpl_config.h"
 #include "vae_kernels.h"
 
 extern int mmpl_set_error(const char* where, const char* what);  // api.hip
@@ -104,6 +105,7 @@ struct Ctx {
   hipError_t err = hipSuccess;
   const char* where = "";
   std::map<std::string, int> ring_base;   // temporal-cache rings: first slot of the two cached frames, per conv volume
+  std::map<std::string, bool> prefilled;  // convs whose new input frames the PRODUCING conv's epilogue already normalised into their ring slots
   size_t plain_elems;
   bf16_t* plain(int i) { return ar.get("plain" + std::to_string(i), plain_elems); }
   void chk(hipError_t e, const char* w) { if (e != hipSuccess && err == hipSuccess) { err = e; where = w; } }
@@ -123,11 +125,44 @@ void norm_into(Ctx& c, const bf16_t* x, int T, int H, int W, int C, const bf16_t
   c.chk(vae_launch_norm(a, c.s), "norm");
 }
 
+// The consumer of a conv's output, when that consumer is a cached 3x3x3 conv behind RMS_norm + SiLU whose padded ring slots the
+// producer's epilogue can fill directly (ConvArgs.ngamma): `name` / `gamma` / output channels `N` of the consumer; everything else (T, Tmax, H, W, channels)
+// is the producer's output geometry.
+struct Fuse { std::string name; const bf16_t* gamma; int N; };
+struct NormDst { const bf16_t* gamma = nullptr; bf16_t* frame[8] = {}; };
+
+// Resolve a Fuse request of a producer with output [T, H, W, C]: the consumer's ring slots for its T new frames, or nothing when
+// either side cannot do it (the fused epilogue exists for the 96-channel halo kernel only; the consumer must read ring slots).
+// Allocates the consumer's volume under the name cached_conv3 will ask for, in the dry pass too.
+NormDst resolve_fuse(Ctx& c, const Fuse* f, bool producer_halo, int T, int Tmax, int H, int W, int C) {
+  NormDst nd;
+  if (!f || mmpl_config().vae_no_fuse_norm) return nd;
+  const size_t slot = (size_t)(H + 2) * (W + 2) * C;
+  const int Tp = Tmax + 2;
+  bf16_t* vol = c.ar.get(f->name + ".pad", (size_t)Tp * slot);
+  if (c.dry || !producer_halo || C != 96 || T > 8) return nd;
+  ConvArgs probe = {};
+  probe.Wfrag = c.v->Wopt(f->name + ".weight.frag"); probe.kt = probe.kh = probe.kw = 3; probe.st = probe.sy = probe.sx = 1;
+  probe.Hp = H + 2; probe.Wp = W + 2; probe.Ho = H; probe.Wo = W; probe.M = T * H * W; probe.Cin = C;
+  probe.N = f->N;
+  if (!vae_conv_uses_halo(probe)) return nd;
+  const int base = c.ring_base[f->name];
+  for (int t = 0; t < T; ++t) nd.frame[t] = vol + (size_t)((base + t + 2) % Tp) * slot;
+  nd.gamma = f->gamma;
+  c.prefilled[f->name] = true;
+  return nd;
+}
+
 void conv(Ctx& c, const bf16_t* src, int Cin, int Hp, int Wp, int st, int sy, int sx, int kt, int kh, int kw, const bf16_t* Wt,
           const bf16_t* bias, int To, int Ho, int Wo, int N, bf16_t* dst, int Hd, int Wd, int ldd, int dt0, int dy0, int dx0,
-          const bf16_t* res, int ldres, const bf16_t* Wfrag = nullptr, const bf16_t* const* frames = nullptr, int n_frames = 0) {
+          const bf16_t* res, int ldres, const bf16_t* Wfrag = nullptr, const bf16_t* const* frames = nullptr, int n_frames = 0,
+          const NormDst* nd = nullptr) {
   if (c.dry) return;
   ConvArgs g = {};
+  if (nd && nd->gamma) {
+    g.ngamma = nd->gamma; g.nscale = sqrtf((float)N);
+    for (int j = 0; j < To && j < 8; ++j) g.nframe[j] = nd->frame[j];
+  }
   g.Wfrag = Wfrag;
   for (int j = 0; j < n_frames && j < 8; ++j) g.frame[j] = frames[j];
   g.src = src; g.Cin = Cin; g.Hp = Hp; g.Wp = Wp; g.st = st; g.sy = sy; g.sx = sx; g.ntaps = kt * kh * kw;
@@ -154,7 +189,7 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const bf16_t* Wt, int ldw, const bf1
 // pass writes the new frames straight into their slots, the kernel is handed the slot pointers, and base advances by T: no copy.
 // (The plain kernel addresses frames linearly, so there the last two frames are copied to the front after every call: 4 % of a decode.)
 void cached_conv3(Ctx& c, const std::string& name, const bf16_t* x, const bf16_t* gamma, int T, int Tmax, int H, int W, int Cin,
-                  int N, bf16_t* out, const bf16_t* res) {
+                  int N, bf16_t* out, const bf16_t* res, const Fuse* fuse = nullptr, bool plain_needed = true) {
   const size_t slot = (size_t)(H + 2) * (W + 2) * Cin;
   const int Tp = Tmax + 2;
   bf16_t* vol = c.ar.get(name + ".pad", (size_t)Tp * slot);
@@ -166,6 +201,7 @@ void cached_conv3(Ctx& c, const std::string& name, const bf16_t* x, const bf16_t
     probe.Ho = H; probe.Wo = W; probe.M = T * H * W; probe.N = N; probe.Cin = Cin;
     ring = vae_conv_uses_halo(probe);
   }
+  const NormDst nd = resolve_fuse(c, fuse, ring, T, Tmax, H, W, N);
   if (!ring) {
     if (x) norm_into(c, x, T, H, W, Cin, gamma, gamma != nullptr, vol, H + 2, W + 2, Cin, 2, 1, 1);
     conv(c, vol, Cin, H + 2, W + 2, 1, 1, 1, 3, 3, 3, c.v->W(name + ".weight"), c.v->W(name + ".bias"), T, H, W, N, out, H, W, N, 0, 0, 0,
@@ -176,24 +212,31 @@ void cached_conv3(Ctx& c, const std::string& name, const bf16_t* x, const bf16_t
   int& base = c.ring_base[name];
   const bf16_t* frames[8];
   for (int j = 0; j < T + 2; ++j) frames[j] = vol + (size_t)((base + j) % Tp) * slot;
-  for (int t = 0; t < T; ++t)
-    norm_into(c, x + (size_t)t * H * W * Cin, 1, H, W, Cin, gamma, gamma != nullptr, const_cast<bf16_t*>(frames[t + 2]), H + 2, W + 2, Cin, 0, 1, 1);
-  conv(c, vol, Cin, H + 2, W + 2, 1, 1, 1, 3, 3, 3, c.v->W(name + ".weight"), c.v->W(name + ".bias"), T, H, W, N, out, H, W, N, 0, 0, 0,
-       res, N, Wfrag, frames, T + 2);
+  auto pre = c.prefilled.find(name);
+  if (pre != c.prefilled.end() && pre->second) {
+    pre->second = false;               // the producer's epilogue wrote frames[2 .. T + 1]
+  } else {
+    for (int t = 0; t < T; ++t)
+      norm_into(c, x + (size_t)t * H * W * Cin, 1, H, W, Cin, gamma, gamma != nullptr, const_cast<bf16_t*>(frames[t + 2]), H + 2, W + 2, Cin, 0, 1, 1);
+  }
+  // (a fused consumer that nothing else reads -- a ResidualBlock's first conv -- needs no plain output at all)
+  conv(c, vol, Cin, H + 2, W + 2, 1, 1, 1, 3, 3, 3, c.v->W(name + ".weight"), c.v->W(name + ".bias"), T, H, W, N,
+       (nd.gamma && !plain_needed) ? nullptr : out, H, W, N, 0, 0, 0, res, N, Wfrag, frames, T + 2, &nd);
   base = (base + T) % Tp;
 }
 
 // ResidualBlock (vae.py:186-220): x [T,H,W,cin] -> out [T,H,W,cout]; x, out, tmp are distinct plain buffers
 void res_block(Ctx& c, const std::string& pre, const bf16_t* x, bf16_t* out, bf16_t* tmp, bf16_t* tmp2, int T, int Tmax, int H, int W,
-               int cin, int cout) {
+               int cin, int cout, const Fuse* next = nullptr) {
   const bf16_t* h = x;
   if (cin != cout) {  // CausalConv3d(in, out, 1): a 1-tap implicit GEMM straight from x
     conv(c, x, cin, H, W, 1, 1, 1, 1, 1, 1, c.v->W(pre + "shortcut.weight"), c.v->W(pre + "shortcut.bias"), T, H, W, cout, tmp2, H, W, cout,
          0, 0, 0, nullptr, 0);
     h = tmp2;
   }
-  cached_conv3(c, pre + "residual.2", x, c.v->W(pre + "residual.0.gamma"), T, Tmax, H, W, cin, cout, tmp, nullptr);
-  cached_conv3(c, pre + "residual.6", tmp, c.v->W(pre + "residual.3.gamma"), T, Tmax, H, W, cout, cout, out, h);
+  const Fuse inner{pre + "residual.6", c.v->W(pre + "residual.3.gamma"), cout};
+  cached_conv3(c, pre + "residual.2", x, c.v->W(pre + "residual.0.gamma"), T, Tmax, H, W, cin, cout, tmp, nullptr, &inner, false);
+  cached_conv3(c, pre + "residual.6", tmp, c.v->W(pre + "residual.3.gamma"), T, Tmax, H, W, cout, cout, out, h, next, true);
 }
 
 // AttentionBlock (vae.py:223-262), per frame, single head of dim C over H*W tokens
@@ -249,7 +292,17 @@ int decoder_frame(Ctx& c, const bf16_t* z_all, int F, int fi, const float* mean,
     int cin = dd[i], cout = dd[i + 1];
     if (i >= 1) cin /= 2;
     for (int r = 0; r < 3; ++r) {
-      res_block(c, "decoder.upsamples." + std::to_string(j) + ".", x, y, t1, t2, T, tmax, H, W, cin, cout);
+      // who reads this block's output behind a norm: the next block's first conv (same width only -- a widening block's 1x1
+      // shortcut is not a ring conv), after the last block of the last stage the head; an upsampler reads it raw
+      Fuse next;
+      const Fuse* nextp = nullptr;
+      if (r < 2) {
+        const std::string np = "decoder.upsamples." + std::to_string(j + 1) + ".";
+        next = Fuse{np + "residual.2", v->W(np + "residual.0.gamma"), cout}; nextp = &next;
+      } else if (i == 3) {
+        next = Fuse{"decoder.head.2", v->W("decoder.head.0.gamma"), 4}; nextp = &next;
+      }
+      res_block(c, "decoder.upsamples." + std::to_string(j) + ".", x, y, t1, t2, T, tmax, H, W, cin, cout, nextp);
       std::swap(x, y);
       cin = cout;
       ++j;
@@ -277,8 +330,16 @@ int decoder_frame(Ctx& c, const bf16_t* z_all, int F, int fi, const float* mean,
         c.chk(vae_launch_upsample(u, c.s), "upsample");
       }
       T = To; H *= 2; W *= 2;
-      conv(c, pu, C, H + 2, W + 2, 1, 1, 1, 1, 3, 3, v->W(pre + "resample.1.weight"), v->W(pre + "resample.1.bias"), T, H, W, C / 2, y, H, W,
-           C / 2, 0, 0, 0, nullptr, 0, v->Wopt(pre + "resample.1.weight.frag"));
+      {  // the upsampler's Conv2d feeds the next stage's first block: its norm goes into this conv's epilogue where it can (C / 2 == 96)
+        const std::string np = "decoder.upsamples." + std::to_string(j + 1) + ".";
+        const Fuse next{np + "residual.2", v->W(np + "residual.0.gamma"), dd[i + 2]};
+        ConvArgs probe = {};
+        probe.Wfrag = v->Wopt(pre + "resample.1.weight.frag"); probe.kt = 1; probe.kh = probe.kw = 3; probe.st = probe.sy = probe.sx = 1;
+        probe.Hp = H + 2; probe.Wp = W + 2; probe.Ho = H; probe.Wo = W; probe.M = T * H * W; probe.Cin = C; probe.N = C / 2;
+        const NormDst nd = resolve_fuse(c, &next, !c.dry && vae_conv_uses_halo(probe), T, tmax, H, W, C / 2);
+        conv(c, pu, C, H + 2, W + 2, 1, 1, 1, 1, 3, 3, v->W(pre + "resample.1.weight"), v->W(pre + "resample.1.bias"), T, H, W, C / 2, y, H, W,
+             C / 2, 0, 0, 0, nullptr, 0, v->Wopt(pre + "resample.1.weight.frag"), nullptr, 0, &nd);
+      }
       std::swap(x, y);
       ++j;
     }

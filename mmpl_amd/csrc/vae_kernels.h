@@ -22,6 +22,12 @@ struct ConvArgs {
   int Hd, Wd, ldd, dt0, dy0, dx0, dc0;
   const bf16_t* res;   // optional residual, plain [M, ldres]
   int ldres;
+  // optional (conv_halo_kernel, N == 96 only: one block owns every channel of its pixels): the CONSUMER's RMS_norm + SiLU
+  // (vae.py:51-54 + nn.SiLU, the `residual.0/3` / `head.0` modules in front of the next conv) applied to this conv's bf16 output in
+  // the epilogue and written into the consumer's padded frame slots -- output frame t, pixel (y, x) -> nframe[t] + ((y + 1) * (Wo + 2)
+  // + x + 1) * N.  dst may then be null (nothing else reads the plain output).
+  const bf16_t* ngamma; float nscale;
+  bf16_t* nframe[8];
 };
 hipError_t vae_launch_conv(const ConvArgs& g, hipStream_t s);
 bool vae_conv_uses_halo(const ConvArgs& g);   // will vae_launch_conv take conv_halo_kernel (the only one that understands ConvArgs.frame)?

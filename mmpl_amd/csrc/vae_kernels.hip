@@ -248,6 +248,75 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     mma(a0, w0);
   }
+  // ---- epilogue with the consumer's RMS_norm + SiLU fused (N == 96: this block holds every channel of its pixels; a pixel's 96
+  // values sit in the 4 lanes frow, frow + 16, frow + 32, frow + 48).  Same arithmetic and rounding points as norm_act_pad_kernel on
+  // the bf16 value this conv stores (vae.py:51-54: x / clamp(bf16(||x||), 1e-12), * sqrt(C), * gamma, each a bf16 tensor; then SiLU);
+  // only the order of the fp32 sum of squares differs.  The norm pass it replaces re-read the plain output from HBM and was
+  // VALU-bound; here the same VALU work runs under the CU's other block's MFMAs.
+  if constexpr (NF == 6) {
+    if (g.ngamma) {
+      float gm[NJ_W][4];
+#pragma unroll
+      for (int j = 0; j < NJ_W; ++j) {
+        const u32x2 gg = *reinterpret_cast<const u32x2*>(g.ngamma + n0 + 16 * j + 4 * fchunk);
+        gm[j][0] = bf2f(gg.x & 0xffff); gm[j][1] = bf2f(gg.x >> 16); gm[j][2] = bf2f(gg.y & 0xffff); gm[j][3] = bf2f(gg.y >> 16);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int y = y0 + ROWS_W * wm + (i >> 1), x = x0 + (i & 1) * 16 + frow;
+        const bool live = y < g.Ho && x < g.Wo;
+        const size_t m = ((size_t)t0 * g.Ho + min(y, g.Ho - 1)) * g.Wo + min(x, g.Wo - 1);
+        float v[NJ_W][4];
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ_W; ++j) {
+          const int n = n0 + 16 * j + 4 * fchunk;
+          const u32x2 bb = *reinterpret_cast<const u32x2*>(g.bias + n);
+          v[j][0] = rbf(acc[i][j][0] + bf2f(bb.x & 0xffff)); v[j][1] = rbf(acc[i][j][1] + bf2f(bb.x >> 16));
+          v[j][2] = rbf(acc[i][j][2] + bf2f(bb.y & 0xffff)); v[j][3] = rbf(acc[i][j][3] + bf2f(bb.y >> 16));
+          if (g.res) {
+            const u32x2 rr = *reinterpret_cast<const u32x2*>(g.res + m * g.ldres + n);
+            v[j][0] = rbf(v[j][0] + bf2f(rr.x & 0xffff)); v[j][1] = rbf(v[j][1] + bf2f(rr.x >> 16));
+            v[j][2] = rbf(v[j][2] + bf2f(rr.y & 0xffff)); v[j][3] = rbf(v[j][3] + bf2f(rr.y >> 16));
+          }
+          if (g.dst && live) {
+            const size_t dpix = ((size_t)(t0 + g.dt0) * g.Hd + (y + g.dy0)) * g.Wd + (x + g.dx0);
+            u32x2 o;
+            o.x = pack2bf(v[j][0], v[j][1]);
+            o.y = pack2bf(v[j][2], v[j][3]);
+            *reinterpret_cast<u32x2*>(g.dst + dpix * g.ldd + g.dc0 + n) = o;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sq += v[j][e] * v[j][e];
+        }
+        sq += __shfl_xor(sq, 16, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        const float denom = fmaxf(rbf(sqrtf(sq)), 1e-12f);
+        float rden = __frcp_rn(denom);
+        rden = fmaf(fmaf(-denom, rden, 1.f), rden, rden);
+        if (!live) continue;
+        bf16_t* np = g.nframe[t0] + ((size_t)(y + 1) * (g.Wo + 2) + (x + 1)) * g.N;
+#pragma unroll
+        for (int j = 0; j < NJ_W; ++j) {
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float q = v[j][e] * rden;
+            q = fmaf(fmaf(-q, denom, v[j][e]), rden, q);      // the correctly rounded fp32 quotient (see norm_act_pad_kernel)
+            float nv = rbf(q);
+            nv = rbf(nv * g.nscale);
+            nv = rbf(nv * gm[j][e]);
+            o[e] = __fdividef(nv, 1.0f + __expf(-nv));
+          }
+          u32x2 w;
+          w.x = pack2bf(o[0], o[1]);
+          w.y = pack2bf(o[2], o[3]);
+          *reinterpret_cast<u32x2*>(np + n0 + 16 * j + 4 * fchunk) = w;
+        }
+      }
+      return;
+    }
+  }
   // ---- epilogue: lane = one output pixel x 4 consecutive output channels per fragment (conv_igemm_kernel's)
 #pragma unroll
   for (int i = 0; i < MI; ++i) {

@@ -37,6 +37,17 @@ def test_compiler_never_touches_m0(tmp_path, src):
 
 
 @hipcc
+def test_gemm_v8_owns_the_accumulator_file(tmp_path):
+    """gemm_bf16_v8_kernel (one wave per SIMD) keeps its 128 x 128 accumulators in a[0:255] by name, like attn_w64.hip: no
+    compiler-generated access to the accumulator file, no spill, no scratch in any of its instantiations.  (hipcc DID park hoisted
+    epilogue addresses in a[1..] until they were derived from an opaque copy of the lane id behind the k loop.)"""
+    import audit_w64
+    problems, info = audit_w64.audit(str(tmp_path), os.path.join(CSRC, "gemm.hip"), own_agprs=True, own_kernels="gemm_bf16_v8_kernel")
+    assert not problems, problems
+    assert len(info["own_kernels"]) == 7, info["own_kernels"]
+
+
+@hipcc
 def test_gemm_register_budget(tmp_path):
     """gemm_bf16_v6_kernel sits at 253-256 of 256 VGPRs; the persistent tile loop, the L2 prefetch shares and the epilogue's gate
     rows cost it 10-14 spilled registers, all of them OUTSIDE the k loop (tile bookkeeping saved before / restored after it).

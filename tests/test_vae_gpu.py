@@ -81,3 +81,38 @@ def test_decode_real_handoff_artefact_vs_oracle():
     e = rel_l2(out, ref)
     print(f"decode of the real hand-off artefact crop: rel_l2(HIP, oracle) = {e:.3e}")
     assert out.shape == (9, 3, 128, 192) and e < 3e-2
+
+
+_CHILD = """
+import sys, torch
+sys.path.insert(0, {root!r})
+from tests.test_vae_gpu import _engine, MEAN, STD
+from mmpl_amd.synthetic import philox_normal
+eng, sd = _engine((6, 10))
+z = philox_normal([3, 16, 6, 10], 77)
+px = philox_normal([3, 9, 48, 80], 78).clamp(-1, 1)
+torch.save({{"dec": eng.decode(z, MEAN, STD).cpu(), "enc": eng.encode(px, MEAN, STD).cpu()}}, sys.argv[1])
+"""
+
+
+def test_norm_fused_into_conv_epilogue_vs_separate_pass(tmp_path):
+    """The RMS_norm + SiLU in front of every 96-channel conv runs in the PRODUCING conv's epilogue (conv_halo_kernel, ConvArgs.ngamma;
+    vae.py:51-54, 186-220).  Same arithmetic and rounding points as the separate pass (MMPL_VAE_NO_FUSE_NORM=1, run in a child
+    process because the switch is read once); only the order of the fp32 sum of squares differs, which can move a pixel's bf16
+    norm by one ulp.  Geometry 48 x 80: ragged 8 x 32 patches."""
+    import os
+    import subprocess
+    import sys
+    from mmpl_amd.synthetic import philox_normal
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    f = tmp_path / "unfused.pt"
+    env = dict(os.environ, MMPL_VAE_NO_FUSE_NORM="1")
+    p = subprocess.run([sys.executable, "-c", _CHILD.format(root=root), str(f)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    ref = torch.load(f)
+    eng, sd = _engine((6, 10))
+    dec = eng.decode(philox_normal([3, 16, 6, 10], 77), MEAN, STD).cpu()
+    enc = eng.encode(philox_normal([3, 9, 48, 80], 78).clamp(-1, 1), MEAN, STD).cpu()
+    ed, ee = rel_l2(dec, ref["dec"]), rel_l2(enc, ref["enc"])
+    print(f"fused vs separate norm pass: decode rel_l2 = {ed:.3e}, encode rel_l2 = {ee:.3e}")
+    assert ed < 3e-3 and ee < 3e-3

@@ -8,8 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "mmpl_amd", "csrc", "attn_w64.hip")
 
 
-def audit(workdir, src=SRC, own_agprs=True):
+def audit(workdir, src=SRC, own_agprs=True, own_kernels=None):
     """own_agprs: the source names accumulator registers literally (attn_w64.hip) -> the compiler must not touch the file.
+    own_kernels: a substring; only the kernels whose (mangled) name contains it own the accumulator file (gemm.hip: the
+    one-wave-per-SIMD gemm_bf16_v8_kernel next to compiler-allocated ones); implies the per-kernel form of the check.
     For every source: m0 (written by the hand-issued LDS-DMA statements without a clobber) must not appear in compiler code."""
     stem = os.path.splitext(os.path.basename(src))[0]
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-c", src, "-o", stem + ".o", "-save-temps"]
@@ -37,7 +39,8 @@ def audit(workdir, src=SRC, own_agprs=True):
             if re.search(r"\bm0\b", t.split(";")[0]):
                 asm_m0[kernel] = asm_m0.get(kernel, 0) + 1
         else:
-            if own_agprs and (t.startswith("v_accvgpr") or re.search(r"\ba\[?\d+", t.split(";")[0])):
+            owns = own_agprs if own_kernels is None else (kernel is not None and own_kernels in kernel)
+            if owns and (t.startswith("v_accvgpr") or re.search(r"\ba\[?\d+", t.split(";")[0])):
                 outside.append((i + 1, t))
             if re.search(r"\bm0\b", t.split(";")[0]):
                 comp_m0.setdefault(kernel, []).append((i + 1, t))
@@ -51,8 +54,13 @@ def audit(workdir, src=SRC, own_agprs=True):
     for key in ("vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size"):
         vals = [int(v) for v in re.findall(rf"\.{key}:\s+(\d+)", asm)]
         info[key] = vals
-        if own_agprs and key != "sgpr_spill_count" and any(vals):
+        if own_agprs and own_kernels is None and key != "sgpr_spill_count" and any(vals):
             problems.append(f"{key} = {vals}")
+    if own_kernels is not None:      # per-kernel metadata of the owning kernels: no spills, no scratch
+        for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", asm):
+            if own_kernels in m.group(1) and (int(m.group(2)) or int(m.group(3))):
+                problems.append(f"{m.group(1)}: scratch {m.group(2)} bytes, {m.group(3)} spilled VGPRs")
+        info["own_kernels"] = sorted(set(k for k in re.findall(r"\.name:\s+(\S+)", asm) if own_kernels in k))
     info["vgpr_count"] = [int(v) for v in re.findall(r"\.vgpr_count:\s+(\d+)", asm)]
     info["agpr_count"] = [int(v) for v in re.findall(r"\.agpr_count:\s+(\d+)", asm)]
     info["sgpr_count"] = [int(v) for v in re.findall(r"\.sgpr_count:\s+(\d+)", asm)]
