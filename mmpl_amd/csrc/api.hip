@@ -432,6 +432,7 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
         for (int i = 0; i < nF; ++i, ++np) {
           a.k_pages[np] = w.ksc + (size_t)i * S * d;
           a.v_pages[np] = w.vsc + (size_t)i * S * d;
+          a.page_group[np] = 1;                      // the workspace, not the cache allocation (order independent of their addresses)
         }
       a.n_pages = np;
       a.variant = self_variant;

@@ -318,8 +318,11 @@ namespace {
 AttnArgs merge_contiguous_pages(const AttnArgs& a) {
   int order[MMPL_MAX_PAGES];
   for (int i = 0; i < a.n_pages; ++i) order[i] = i;
-  for (int i = 1; i < a.n_pages; ++i)                      // insertion sort by K address
-    for (int j = i; j > 0 && a.k_pages[order[j]] < a.k_pages[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+  auto before = [&a](int x, int y) {                      // (allocation group, K address): see AttnArgs.page_group
+    return a.page_group[x] != a.page_group[y] ? a.page_group[x] < a.page_group[y] : a.k_pages[x] < a.k_pages[y];
+  };
+  for (int i = 1; i < a.n_pages; ++i)                      // insertion sort
+    for (int j = i; j > 0 && before(order[j], order[j - 1]); --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
   const size_t kstride = (size_t)a.page_rows * a.ldk, vstride = (size_t)a.page_rows * a.ldv;
   // (the kernel addresses a page with 32-bit byte offsets / a buffer descriptor: a merged page stays below 2 GiB)
   const size_t per_page = 2 * (kstride > vstride ? kstride : vstride);
@@ -328,8 +331,8 @@ AttnArgs merge_contiguous_pages(const AttnArgs& a) {
   m.n_pages = 0;
   for (int i = 0; i < a.n_pages;) {
     int r = 1;
-    while (i + r < a.n_pages && r < max_run && a.k_pages[order[i + r]] == a.k_pages[order[i + r - 1]] + kstride &&
-           a.v_pages[order[i + r]] == a.v_pages[order[i + r - 1]] + vstride)
+    while (i + r < a.n_pages && r < max_run && a.page_group[order[i + r]] == a.page_group[order[i]] &&
+           a.k_pages[order[i + r]] == a.k_pages[order[i + r - 1]] + kstride && a.v_pages[order[i + r]] == a.v_pages[order[i + r - 1]] + vstride)
       ++r;
     m.k_pages[m.n_pages] = a.k_pages[order[i]];
     m.v_pages[m.n_pages] = a.v_pages[order[i]];

@@ -773,11 +773,14 @@ struct G8 {
   uint32_t ra[2][2], rw[2][2];    // fragment-0 LDS read address [stage][half]; fragment i at + 2048 i
   uint32_t a_vo[8], w_vo[8];      // per-piece LDS-DMA source byte offsets (constant over k)
   const bf16_t* a_k; const bf16_t* w_k;   // operand base of the next k-tile to fetch
+  const bf16_t* a_last; const bf16_t* w_last;   // ... of the last k-tile
   uint32_t dst0;                  // LDS address of this wave's piece 0 of stage 0's activation half (piece q at + 4096 q)
+  uint32_t pf_wo, pf_ao, pf_dump; // L2 prefetch (GEMM8_PF): this lane's byte offsets into the tile's shares of W and A, dump address
 
-  template <int KS, int I, int J> MMPL_DEV void mfma() {
+  template <int KS, int I, int J, bool ZERO = false> MMPL_DEV void mfma() {      // ZERO: C = 0 (a tile's very first MFMA per accumulator)
     constexpr int c = 4 * (8 * I + J);
-    asm volatile("v_mfma_f32_16x16x32_bf16 a[%c0:%c1], %2, %3, a[%c0:%c1]" ::"i"(c), "i"(c + 3), "v"(wf[KS][J]), "v"(af[KS][I]));
+    if constexpr (ZERO) asm volatile("v_mfma_f32_16x16x32_bf16 a[%c0:%c1], %2, %3, 0" ::"i"(c), "i"(c + 3), "v"(wf[KS][J]), "v"(af[KS][I]));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 a[%c0:%c1], %2, %3, a[%c0:%c1]" ::"i"(c), "i"(c + 3), "v"(wf[KS][J]), "v"(af[KS][I]));
   }
   template <int S, int KS, int R> MMPL_DEV void lds() {      // fragment R of half KS of the tile in stage S: weights first, then activations
     if constexpr (GEMM8_ABL & 4) return;
@@ -791,6 +794,16 @@ struct G8 {
     if constexpr (Q < 8) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(a_vo[q]), "s"(a_k), "s"(m) : "memory");
     else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(w_vo[q]), "s"(w_k), "s"(m) : "memory");
   }
+  // v6's L2 prefetch of the tile's SHARE of its operand slices (see gemm_bf16_v6_kernel), one k-tile ahead of the ring's DMA: two
+  // LDS-DMA dwords per wave into a dump area nobody reads.  ALWAYS two ops per wave and k-tile (lanes outside the share repeat
+  // lane 0's address), so that the loop's counted vmcnt waits stay compile-time constants.
+  MMPL_DEV void prefetch() {
+    if constexpr (GEMM8_ABL & 1) return;
+    const bf16_t* pw = w_k + BK4 <= w_last ? w_k + BK4 : w_last;      // (past the last k-tile: that tile again, never past the row)
+    const bf16_t* pa = a_k + BK4 <= a_last ? a_k + BK4 : a_last;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(pf_wo), "s"(pw), "s"(pf_dump) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(pf_ao), "s"(pa), "s"(pf_dump + 256u) : "memory");
+  }
 };
 
 // gap placement of one k-tile (dev sweep: -DGEMM8_...)
@@ -803,15 +816,18 @@ struct G8 {
 #ifndef GEMM8_BAR2
 #define GEMM8_BAR2 30        // phase 2: vmcnt + barrier, then the next tile's first-half reads in gaps BAR2 + 2, + 4, ..
 #endif
+#ifndef GEMM8_PF
+#define GEMM8_PF 1           // 1: two L2 prefetch ops per wave and k-tile behind the DMA pieces (G8::prefetch)
+#endif
 // S: ring stage of this tile; ISSUE: tile t+2 exists (fetch it into stage S); NEXT: tile t+1 exists (read its first half)
-template <int S, bool ISSUE, bool NEXT> MMPL_DEV void gemm8_tile(G8& k) {
+template <int S, bool ISSUE, bool NEXT, bool FIRST = false> MMPL_DEV void gemm8_tile(G8& k) {
   constexpr int D1 = GEMM8_BAR1 + 2;                                   // first DMA gap of phase 1
   constexpr int N1 = (64 - D1 + GEMM8_DMAS - 1) / GEMM8_DMAS;          // pieces issued in phase 1
-  static_assert(N1 >= 0 && N1 <= 16 && (16 - N1) * GEMM8_DMAS < GEMM8_BAR2 && GEMM8_BAR2 + 2 + 2 * 15 < 64, "placement");
+  static_assert(N1 >= 0 && N1 <= 16 && (16 - N1) * GEMM8_DMAS + 1 < GEMM8_BAR2 && GEMM8_BAR2 + 2 + 2 * 15 < 64, "placement");
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // this tile's first-half fragments
   sfor<64>([&k](auto gi) {
     constexpr int g = decltype(gi)::value;
-    k.template mfma<0, g / 8, g % 8>();
+    k.template mfma<0, g / 8, g % 8, FIRST>();
     if constexpr ((g & 1) == 0 && g < 32) k.template lds<S, 1, g / 2>();
     if constexpr (g == GEMM8_BAR1 && !(GEMM8_ABL & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if constexpr (ISSUE && g >= D1 && (g - D1) % GEMM8_DMAS == 0) k.template dma<S, (g - D1) / GEMM8_DMAS>();
@@ -820,8 +836,10 @@ template <int S, bool ISSUE, bool NEXT> MMPL_DEV void gemm8_tile(G8& k) {
     constexpr int g = decltype(gi)::value;
     k.template mfma<1, g / 8, g % 8>();
     if constexpr (ISSUE && g % GEMM8_DMAS == 0 && N1 + g / GEMM8_DMAS < 16) k.template dma<S, N1 + g / GEMM8_DMAS>();
+    if constexpr (ISSUE && GEMM8_PF && g == (16 - N1) * GEMM8_DMAS) k.prefetch();
     if constexpr (NEXT && g == GEMM8_BAR2 && !(GEMM8_ABL & 8)) {
-      if constexpr (ISSUE) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+      // in flight, oldest first: tile t+1's 16 pieces [+ 2 prefetch ops], tile t+2's 16 [+ 2]: everything but the first 16 may be
+      if constexpr (ISSUE) asm volatile("s_waitcnt vmcnt(%c0)\n\ts_barrier" ::"i"(GEMM8_PF ? 20 : 16) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
     if constexpr (NEXT && g > GEMM8_BAR2 && ((g - GEMM8_BAR2) & 1) == 0 && (g - GEMM8_BAR2) / 2 <= 16) k.template lds<S ^ 1, 0, (g - GEMM8_BAR2) / 2 - 1>();
@@ -865,6 +883,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         k.rw[s][ks] = ring + s * STAGE4 + A4_BYTES + (swz64(128 * wn + frow, fchunk) ^ (ks << 6));
       }
     k.dst0 = ring + 1024 * wave;
+    k.pf_dump = ring + 2 * STAGE4 + 512 * wave;
   }
   const int prow = lane >> 3, lc = ((lane & 7) ^ (prow & 7)) << 3;     // row within a piece, swizzled source chunk (elements)
   const int nt = g.K / BK4;
@@ -901,21 +920,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       k.w_vo[q] = (uint32_t)(min(n0 + 8 * p + prow, g.N - 1) * g.ldw + lc) * 2u;
     }
     k.a_k = g.A; k.w_k = g.W;
-    sfor<256>([](auto ii) { asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(decltype(ii)::value)); });
+    k.a_last = g.A + (size_t)(nt - 1) * BK4; k.w_last = g.W + (size_t)(nt - 1) * BK4;
+    if constexpr (GEMM8_PF) {
+      // the share of this tile: rows tm_l * 256 / gsz ... of its W panel (the gsz tiles of a column panel split it), rows
+      // (tn % P) * 256 / P ... of its A panel (P = 32 / gsz tiles of a row panel in flight on the XCD); one 64-byte half line per
+      // lane, 256 lanes of the block = wave * 64 + lane; lanes past a share repeat its first line.  g.pf_dist == 0: own first rows.
+      const int P = 32 / gsz, nw = 2 * (256 / gsz), na = 2 * (256 / P);
+      const int l = wave * 64 + lane;
+      const int wrow0 = n0 + ((bid % per_group) % gsz) * (256 / gsz), arow0 = m0 + (tn % P) * (256 / P);
+      const int lw = (g.pf_dist > 0 && l < nw) ? l : 0, la = (g.pf_dist > 0 && l < na) ? l : 0;
+      k.pf_wo = (uint32_t)(min(wrow0 + (lw >> 1), g.N - 1) * g.ldw + (lw & 1) * 32) * 2u;
+      k.pf_ao = (uint32_t)(min(arow0 + (la >> 1), g.M - 1) * g.lda + (la & 1) * 32) * 2u;
+    }
+    // (accumulators: zeroed by the first k-tile's MFMAs themselves, C = 0, whenever the peeled first pair below exists)
+    if (nt < 4) sfor<256>([](auto ii) { asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(decltype(ii)::value)); });
 
     // ---- prologue: tiles 0 and 1 into the two stages, tile 0's first-half fragments into registers
     sfor<16>([&k](auto q) { k.template dma<0, decltype(q)::value>(); });
     k.a_k += BK4; k.w_k += BK4;
     if (nt > 1) {
       sfor<16>([&k](auto q) { k.template dma<1, decltype(q)::value>(); });
+      if constexpr (GEMM8_PF) k.prefetch();                          // (same queue pattern as a loop iteration: 16 pieces, 2 prefetch ops)
       k.a_k += BK4; k.w_k += BK4;
-      asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%c0)\n\ts_barrier" ::"i"(GEMM8_PF ? 18 : 16) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
     sfor<16>([&k](auto r) { k.template lds<0, 0, decltype(r)::value>(); });
 
     int t = 0;
+    if (nt >= 4) {
+      gemm8_tile<0, true, true, true>(k);
+      gemm8_tile<1, true, true>(k);
+      t = 2;
+    }
 #pragma unroll 1
     for (; t + 3 < nt; t += 2) {
       gemm8_tile<0, true, true>(k);
@@ -968,10 +1006,10 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
   constexpr int smem = 2 * STAGE4 + 1024;        // ring + the L2 prefetch's dump area
   if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v6_kernel<EPI>), smem); e != hipSuccess) return e;
   if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v6_kernel<EPI, true>), smem); e != hipSuccess) return e;
-  if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v8_kernel<EPI>), 2 * STAGE4); e != hipSuccess) return e;
+  if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v8_kernel<EPI>), 2 * STAGE4 + 2048); e != hipSuccess) return e;
   // main-launch kernel: v8 (one wave per SIMD, 128 x 128 per wave) or v6 (two, 128 x 64).  MMPL_GEMM_V8 = 1 / 0 forces it.
   const int env_v8 = mmpl_config().gemm_v8;
-  const bool use_v8 = env_v8 >= 0 ? env_v8 != 0 : false;
+  const bool use_v8 = env_v8 >= 0 ? env_v8 != 0 : g.N >= 8192;       // the wide GEMMs (qkv, ffn0): profiles/r04c_gemm_v8_*.log
   const int tiles = ((g.M + BM3 - 1) / BM3) * ((g.N + BN3 - 1) / BN3);
   GemmArgs g2 = g;
   const MmplRuntimeConfig& rc = mmpl_config();
@@ -1024,7 +1062,7 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
     if (sp >= 2 && (size_t)8 * tb * sp * (BM3 * BN3 * sizeof(float)) <= mmpl_gemm_splitk_ws_bytes()) {
       g2.splitk_s = sp; g2.splitk_tb = tb;
       if (main_tiles > 0) {
-        if (use_v8) hipLaunchKernelGGL(gemm_bf16_v8_kernel<EPI>, dim3(main_tiles < n_cu ? main_tiles : n_cu), dim3(256), 2 * STAGE4, s, g2);
+        if (use_v8) hipLaunchKernelGGL(gemm_bf16_v8_kernel<EPI>, dim3(main_tiles < n_cu ? main_tiles : n_cu), dim3(256), 2 * STAGE4 + 2048, s, g2);
         else hipLaunchKernelGGL(gemm_bf16_v6_kernel<EPI>, dim3(main_tiles < n_cu ? main_tiles : n_cu), dim3(512), smem, s, g2);
       }
       hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, true>), dim3(8 * tb * sp), dim3(512), smem, s, g2);
@@ -1033,7 +1071,7 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
   }
   const int blocks = g2.tile_counter && tiles > n_cu ? n_cu : tiles;
   if (blocks == tiles) g2.tile_counter = nullptr;             // one round or less: nothing to balance
-  if (use_v8) hipLaunchKernelGGL(gemm_bf16_v8_kernel<EPI>, dim3(blocks), dim3(256), 2 * STAGE4, s, g2);
+  if (use_v8) hipLaunchKernelGGL(gemm_bf16_v8_kernel<EPI>, dim3(blocks), dim3(256), 2 * STAGE4 + 2048, s, g2);
   else hipLaunchKernelGGL(gemm_bf16_v6_kernel<EPI>, dim3(blocks), dim3(512), smem, s, g2);
   return hipGetLastError();
 }

@@ -54,6 +54,11 @@ struct AttnArgs {
   int ldk, ldv;
   int n_pages, page_rows;
   int page_rows_each[MMPL_MAX_PAGES];   // attn_w64_kernel only, filled by mmpl_launch_attention: rows of page p (merged runs of slots differ in length)
+  // host side only (merge_contiguous_pages): which ALLOCATION page p lies in, as the caller knows it (the DiT forward: 0 = KV-cache
+  // slots, 1 = the stage's scratch pages).  Pages are ordered by (group, address) and merged within a group only, so the order and
+  // the tile boundaries the kernel sees -- hence the fp32 summation order, hence the bits -- do not depend on where the allocator
+  // happened to put one allocation relative to another (a fresh process and a long-lived one must agree: tests/test_wavefront_gpu.py).
+  unsigned char page_group[MMPL_MAX_PAGES];
   int Lq, H;
   float scale;                     // softmax scale (1/sqrt(128))
   int cross;                       // 1: text cross-attention launch (symbol tag only)

@@ -98,12 +98,16 @@ torch.save({{"dec": eng.decode(z, MEAN, STD).cpu(), "enc": eng.encode(px, MEAN, 
 def test_norm_fused_into_conv_epilogue_vs_separate_pass(tmp_path):
     """The RMS_norm + SiLU in front of every 96-channel conv runs in the PRODUCING conv's epilogue (conv_halo_kernel, ConvArgs.ngamma;
     vae.py:51-54, 186-220).  Same arithmetic and rounding points as the separate pass (MMPL_VAE_NO_FUSE_NORM=1, run in a child
-    process because the switch is read once); only the order of the fp32 sum of squares differs, which can move a pixel's bf16
-    norm by one ulp.  Geometry 48 x 80: ragged 8 x 32 patches."""
+    process because the switch is read once); only the order of the fp32 sum of squares differs, which moves a pixel's bf16 norm
+    by one ulp now and then.  In the decoder those layers are the LAST stage (measured distance between the two builds 1.9e-4); in
+    the encoder they are the FIRST, and the bf16 network behind them amplifies any perturbation to its own rounding-noise level
+    (3.3e-3; the reference's bf16-vs-fp32 distance for an encode is 7.7e-3) -- so the statement that matters is the second one:
+    both builds are equally close to the oracle.  Geometry 48 x 80: ragged 8 x 32 patches."""
     import os
     import subprocess
     import sys
     from mmpl_amd.synthetic import philox_normal
+    from oracle import vae_ref
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     f = tmp_path / "unfused.pt"
     env = dict(os.environ, MMPL_VAE_NO_FUSE_NORM="1")
@@ -111,8 +115,16 @@ def test_norm_fused_into_conv_epilogue_vs_separate_pass(tmp_path):
     assert p.returncode == 0, p.stderr[-2000:]
     ref = torch.load(f)
     eng, sd = _engine((6, 10))
-    dec = eng.decode(philox_normal([3, 16, 6, 10], 77), MEAN, STD).cpu()
-    enc = eng.encode(philox_normal([3, 9, 48, 80], 78).clamp(-1, 1), MEAN, STD).cpu()
+    z = philox_normal([3, 16, 6, 10], 77)
+    px = philox_normal([3, 9, 48, 80], 78).clamp(-1, 1)
+    dec = eng.decode(z, MEAN, STD).cpu()
+    enc = eng.encode(px, MEAN, STD).cpu()
     ed, ee = rel_l2(dec, ref["dec"]), rel_l2(enc, ref["enc"])
-    print(f"fused vs separate norm pass: decode rel_l2 = {ed:.3e}, encode rel_l2 = {ee:.3e}")
-    assert ed < 3e-3 and ee < 3e-3
+    o_dec = vae_ref.decode_to_pixel(sd, z.unsqueeze(0), MEAN, STD)[0]
+    o_enc = vae_ref.encode_to_latent(sd, px.unsqueeze(0).to(torch.bfloat16), MEAN, STD)[0]
+    fd, ud = rel_l2(dec, o_dec), rel_l2(ref["dec"], o_dec)
+    fe, ue = rel_l2(enc, o_enc), rel_l2(ref["enc"], o_enc)
+    print(f"fused vs separate norm pass: decode rel_l2 = {ed:.3e}, encode rel_l2 = {ee:.3e}; vs the oracle: decode fused {fd:.3e} / separate "
+          f"{ud:.3e}, encode fused {fe:.3e} / separate {ue:.3e}")
+    assert ed < 1e-3 and ee < 6e-3
+    assert fd < 1.1 * ud + 5e-4 and fe < 1.1 * ue + 5e-4
