@@ -51,7 +51,11 @@ constexpr int QB = 256, KVB = 64, TILE = KVB * 256, RING = 4;         // K ring 
 constexpr int W64_SMEM = 2 * RING * TILE + 64;     // + the block's redo flag
 constexpr float BOUND_GEN = 1073741824.f;                              // 2^30: a GENERAL tile's partial row sums
 constexpr float FAST_L_MIN = 7.888609e-31f, FAST_L_MAX = 1.2676506e30f;       // 2^-100, 2^100: a FAST pass's final row sums
-constexpr float FAST_REF_OFFSET = 64.f;       // FAST pass: m_ref = (largest score of the block's first KV tile) + this
+constexpr float FAST_REF_OFFSET = 64.f;       // FAST pass: m_ref = (largest score of the block's first FAST_REF_TILES KV tiles) + this
+#ifndef W64_REF_TILES
+#define W64_REF_TILES 4
+#endif
+constexpr int FAST_REF_TILES = W64_REF_TILES;  // 1 .. 4 (= RING: the tiles the prologue fetches before the pipeline starts)
 
 using w64::sfor;
 #define ALL_AGPRS MMPL_ALL_AGPRS
@@ -414,6 +418,25 @@ template <int MODE> MMPL_DEV void w64_pass(Ctx& k) {
     sfor<16>([&k](auto gi) { k.template mfma_qk<1, decltype(gi)::value>(); });
     k.mfma_write_pad();
     float mx = k.score_max();
+    if (T > FAST_REF_TILES) {
+      // ... and of KV tiles 1 .. 3, which the prologue above already sent on their way into ring slots 1 .. 3: four times the
+      // sample for ~0.2 % more MFMAs per block (all full tiles strictly before the block's last one; T is block-uniform)
+      sfor<FAST_REF_TILES - 1>([&k, &mx](auto ei) {
+        constexpr int e = decltype(ei)::value + 1;
+        // in flight, oldest first: K0 | K1 V0 | K2 V1 | K3 V2 (4 pieces each): K(e) has landed when at most 24 - 8 e are outstanding
+        asm volatile("s_waitcnt vmcnt(%c0)\n\ts_barrier" ::"i"(24 - 8 * e) : "memory");
+        k.kaddr = k.kbase + e * TILE;
+        sfor<16>([&k](auto gi) { k.template lds_k<decltype(gi)::value>(); });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        sfor<16>([&k](auto gi) { k.template mfma_qk<0, decltype(gi)::value>(); });
+        sfor<16>([&k](auto gi) { k.template mfma_qk<1, decltype(gi)::value>(); });
+        k.mfma_write_pad();
+        mx = fmaxf(mx, k.score_max());
+      });
+      k.kaddr = k.kbase;                                 // the K(0) fragments again: the pipeline starts from them
+      sfor<16>([&k](auto gi) { k.template lds_k<decltype(gi)::value>(); });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     mx = fminf(fmaxf(mx, -1e30f), 1e30f);              // (a NaN / inf score: the end-of-pass check fails and GENERAL takes over)
     k.mref[0] = k.mref[1] = mx + FAST_REF_OFFSET;

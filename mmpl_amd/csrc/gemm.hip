@@ -817,8 +817,8 @@ struct G8 {
 #define GEMM8_BAR2 30        // phase 2: vmcnt + barrier, then the next tile's first-half reads in gaps BAR2 + 2, + 4, ..
 #endif
 #ifndef GEMM8_PF
-#define GEMM8_PF 1           // 1: two L2 prefetch ops per wave and k-tile behind the DMA pieces (G8::prefetch)
-#endif
+#define GEMM8_PF 0           // 1: two L2 prefetch ops per wave and k-tile behind the DMA pieces (G8::prefetch).  Measured on v8
+#endif                       // (profiles/r04d_gemm_v8_sweep.log): ffn2 +4 % (= v6's level), but qkv -1 %, ffn0 -4 %: off, ffn2 stays on v6
 // S: ring stage of this tile; ISSUE: tile t+2 exists (fetch it into stage S); NEXT: tile t+1 exists (read its first half)
 template <int S, bool ISSUE, bool NEXT, bool FIRST = false> MMPL_DEV void gemm8_tile(G8& k) {
   constexpr int D1 = GEMM8_BAR1 + 2;                                   // first DMA gap of phase 1

@@ -1,7 +1,7 @@
 """Generate golden fixtures by running the REAL reference (/root/reference, CPU, bf16) on seeded inputs.
 
 Build-container only (the reference never travels to the GPU box).  Usage:
-    python tests/golden/make_golden.py [dit] [chunk] [chunk50] [sched] [vae]
+    python tests/golden/make_golden.py [dit] [chunk] [chunk50] [chunk50_gpu] [sched] [vae]
 Writes tests/golden/*.pt.  Inputs are regenerated from seeds by the tests (mmpl_amd.synthetic), so the
 fixtures hold expected OUTPUTS of the reference (full or strided + sha256), plus known-answer scalars.
 While generating, the oracle restatement (oracle/) is run on the same inputs and its agreement with the
@@ -255,6 +255,34 @@ def gen_chunk50(steps=50):
                os.path.join(HERE, "chunk_t2v_tiny_50.pt"))
 
 
+def gen_chunk50_gpu_semantics(steps=50):
+    """The same 408-forward chunk under the scalar semantics of the reference's NATIVE platform.  The committed chunk50 fixture is
+    the reference run on a CPU, where PyTorch rounds the UniPC step's 0-dim fp32 scalars to bf16 when they are the first operand of
+    a multiply (`sigma_t * x`, fm_solvers_unipc.py:315-331 and the predictor / corrector updates); its GPU kernels keep them in fp32
+    (oracle/unipc_ref.py).  The reference's scheduler source cannot be made to multiply tensor-first without editing it, so this
+    fixture is produced by the ORACLE (bit-exact to the reference forward by forward, 6.3e-3 = the reference's own order noise from
+    it after 408 forwards with the switch off -- chunk50 above) with `gpu_scalar_semantics=True`: nothing but the operand order of
+    those scalar products changes.  Stored with it: its distance to the CPU-semantics fixture (2.3e-2: what the platform alone
+    does to the trajectory) and to the reference's fp32 run (1.6e-2: the GPU semantics are the more accurate ones)."""
+    fx = torch.load(os.path.join(HERE, "chunk_t2v_tiny_50.pt"))
+    m = fx["meta"]
+    cfg = WAN_CONFIGS[m["cfg"]]
+    sd = dit_state_dict(cfg, seed=m["weight_seed"])
+    ctxs = [make_context(cfg, s_, nv)[0] for s_, nv in zip(m["ctx_seeds"], m["n_valid"])]
+    noise = philox_normal([1, 21, 16, H, Wd], m["noise_seed"])
+    renoise = {f: philox_normal([1, 16, H, Wd], m["renoise_seed_base"] + f) for f in (4, 9, 13, 18)}
+    t0 = time.time()
+    out, hand, _ = stage_ref.run_chunk(sd, W.DitCfg(**cfg), noise, ctxs[0], ctxs[1], renoise, None, "t2v", m["guidance"], steps, m["shift"],
+                                       gpu_scalar_semantics=True)
+    d = dict(vs_cpu_semantics_out=rel_l2(out[..., ::2, ::2], fx["out_strided"]), vs_cpu_semantics_handoff=rel_l2(hand[..., ::3, ::3], fx["handoff_strided"]),
+             vs_f32_out=rel_l2(out[..., ::2, ::2], fx["out_f32_strided"]))
+    print(f"[chunk50_gpu] oracle, GPU scalar semantics: {time.time() - t0:.1f}s  vs the reference's CPU run: out={d['vs_cpu_semantics_out']:.3e} "
+          f"handoff={d['vs_cpu_semantics_handoff']:.3e}; vs the reference's fp32 run: {d['vs_f32_out']:.3e}", flush=True)
+    torch.save(dict(out_sha=sha(out), out_strided=out[..., ::2, ::2].clone(), handoff_sha=sha(hand), handoff_strided=hand[..., ::3, ::3].clone(),
+                    distances=d, produced_by="oracle/stage_ref.run_chunk(gpu_scalar_semantics=True); see make_golden.py gen_chunk50_gpu_semantics",
+                    meta=dict(m)), os.path.join(HERE, "chunk_t2v_tiny_50_gpu_semantics.pt"))
+
+
 def gen_sched():
     _, _, _, _, unipc, sched = load_reference()
     s = unipc.FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
@@ -304,6 +332,8 @@ if __name__ == "__main__":
         gen_chunk()
     if "chunk50" in what:
         gen_chunk50()
+    if "chunk50_gpu" in what:
+        gen_chunk50_gpu_semantics()
     if "vae" in what:
         from make_golden_vae import gen_vae
         gen_vae()

@@ -6,13 +6,15 @@ Fixture `tests/golden/chunk_t2v_tiny_50.pt` (tests/golden/make_golden.py chunk50
 CFG 5.0, shift 5.0, 50 steps, plus the reference's own noise floor over that trajectory:
     reference vs itself, only the K/V gather order of its self-attention changed ............ `order_out`   (6.6e-3)
     reference bf16 vs the same weights in fp32 ............................................... `f32_out`     (2.6e-2)
-Measured (profiles/r04a_trajectory.log): HIP vs the reference 2.3e-2, HIP vs the reference's fp32 run 1.6e-2 -- i.e. the HIP chunk
-is CLOSER to exact arithmetic than the reference's own bf16 run is (2.6e-2), and as far from the reference's bf16 output as two
-bf16 executors of the same algorithm are (the oracle -- the same PyTorch ops -- moved to another host CPU lands at the same
-distance: tests/test_oracle_golden.py with MMPL_FULL_TRAJ=1 on the GPU box).  A change of the K/V gather order alone is a far
-gentler perturbation (one fp32 summation order per attention call) than a second implementation (every GEMM / softmax / norm
-accumulates in another order, ~2.5e-3 per forward), so `order_out` is reported but is not the bound.
-Stated tolerance after 408 forwards: rel-L2(HIP, reference bf16) <= rel-L2(reference bf16, reference fp32) AND
+Measured (profiles/r04b_trajectory.log, r04d_traj_executor_floor.log): HIP vs the reference's CPU run 2.3e-2, HIP vs the reference's
+fp32 run 1.6e-2.  Where the 2.3e-2 comes from was then pinned down: PyTorch's CPU kernels round the UniPC step's 0-dim fp32 scalars to
+bf16, its GPU kernels do not (oracle/unipc_ref.py), and over 50 steps x CFG 5 that alone moves the trajectory by 2.29e-2 -- the oracle
+with nothing but that switch flipped, on the same CPU, lands 2.290e-2 from the fixture and 1.582e-2 from the fp32 run, and the
+oracle's ops executed by PyTorch ON THE DEVICE land at 2.292e-2 / 1.582e-2: the same two numbers as the HIP pipeline.  The reference's
+native platform is the GPU, and its semantics are the more accurate ones (1.6e-2 vs 2.6e-2 from fp32).  Hence three tests: against the
+CPU fixture (bound: the reference's own bf16-vs-fp32 distance), against the committed GPU-semantics fixture and against the
+reference's algorithm executed on the device (bound for both: 2 x the reference's K/V-order noise, 1.3e-2).
+Stated tolerance after 408 forwards vs the CPU fixture: rel-L2(HIP, reference bf16) <= rel-L2(reference bf16, reference fp32) AND
 rel-L2(HIP, reference fp32) <= rel-L2(reference bf16, reference fp32).  All numbers are printed."""
 import pytest
 import torch
@@ -41,15 +43,27 @@ def _hip_chunk(pipe, noise, renoise, initial=None):
     return lat.cpu(), got["h"].cpu()
 
 
+_CACHE = {}
+
+
+def _hip_50():
+    """The HIP pipeline's 408-forward chunk at 60x104 (step hipGraphs on), computed once for the three tests that read it."""
+    if "r" not in _CACHE:
+        from tests.test_pipeline_gpu import _setup
+        m = torch.load(f"{GOLDEN}/chunk_t2v_tiny_50.pt")["meta"]
+        pipe, sd, _, cfg, ctx = _setup("t2v", steps=50, lat=(H, Wd))          # same seeds as the fixture's meta (weights 2, ctx 21 / 22, noise 23)
+        assert pipe.sampling_steps == 50
+        noise, renoise = _inputs((H, Wd), m["noise_seed"])
+        _CACHE["r"] = _hip_chunk(pipe, noise, renoise)
+    return _CACHE["r"]
+
+
 def test_t2v_chunk_50_steps_vs_reference_fixture():
     from tests.test_pipeline_gpu import _setup
     fx = torch.load(f"{GOLDEN}/chunk_t2v_tiny_50.pt")
     m, nf = fx["meta"], fx["noise_floor"]
     assert m["steps"] == 50 and m["guidance"] == 5.0 and m["shift"] == 5.0
-    pipe, sd, _, cfg, ctx = _setup("t2v", steps=50, lat=(H, Wd))          # same seeds as the fixture's meta (weights 2, ctx 21 / 22, noise 23)
-    assert pipe.sampling_steps == 50
-    noise, renoise = _inputs((H, Wd), m["noise_seed"])
-    lat, hand = _hip_chunk(pipe, noise, renoise)
+    lat, hand = _hip_50()
     e_out = rel_l2(lat[..., ::2, ::2], fx["out_strided"])
     e_hand = rel_l2(hand[..., ::3, ::3], fx["handoff_strided"])
     e_f32 = rel_l2(lat[..., ::2, ::2], fx["out_f32_strided"])
@@ -60,6 +74,59 @@ def test_t2v_chunk_50_steps_vs_reference_fixture():
     # as close to the reference's bf16 output as that output is to exact arithmetic, and no further from exact arithmetic than it
     assert e_out <= nf["f32_out"] and e_hand <= nf["f32_handoff"]
     assert e_f32 <= nf["f32_out"]
+
+
+def test_t2v_chunk_50_steps_vs_reference_algorithm_on_its_native_platform():
+    """The fixture was produced by the reference on a CPU; the reference's platform is a GPU, and PyTorch's CPU kernels round the
+    UniPC step's 0-dim fp32 scalars to bf16 where its GPU kernels keep them in fp32 (oracle/unipc_ref.py) -- a systematic difference
+    that the 50-step x CFG-5 trajectory amplifies.  Measured (profiles/r04d_traj_executor_floor.log): the oracle's ops -- the
+    reference's own PyTorch ops, restated -- executed ON THE DEVICE land 2.29e-2 from the CPU fixture and 1.58e-2 from the fp32 run,
+    the same distances as the HIP pipeline (2.29e-2 / 1.58e-2).  So the 408-forward statement with the platform difference taken
+    out is HIP against the reference's algorithm run by PyTorch on the device, bound: 2 x the reference's own distance to itself
+    when only its K/V gather order changes (VERDICT r3 item 1's criterion)."""
+    from mmpl_amd.synthetic import WAN_CONFIGS, dit_state_dict, philox_normal
+    from oracle import stage_ref
+    from oracle import wan_dit_ref as W
+    from tests.test_pipeline_gpu import _setup
+    fx = torch.load(f"{GOLDEN}/chunk_t2v_tiny_50.pt")
+    m, nf = fx["meta"], fx["noise_floor"]
+    noise, renoise = _inputs((H, Wd), m["noise_seed"])
+    lat, hand = _hip_50()
+    dev = "cuda:0"
+    cfg = WAN_CONFIGS[m["cfg"]]
+    sd = {k: v.to(dev) for k, v in dit_state_dict(cfg, seed=m["weight_seed"]).items()}
+    ctxs = []
+    for seed, nv in zip(m["ctx_seeds"], m["n_valid"]):
+        c = philox_normal([512, cfg["text_dim"]], seed)
+        c[nv:] = 0
+        ctxs.append(c.to(dev))
+    with torch.device(dev):
+        o_out, o_hand, _ = stage_ref.run_chunk(sd, W.DitCfg(**cfg), noise.to(dev), ctxs[0], ctxs[1], {k: v.to(dev) for k, v in renoise.items()},
+                                               None, "t2v", m["guidance"], m["steps"], m["shift"])
+    torch.cuda.synchronize()
+    o_out, o_hand = o_out.cpu(), o_hand.cpu()
+    e_ref = rel_l2(o_out[..., ::2, ::2], fx["out_strided"])
+    e, eh = rel_l2(lat, o_out), rel_l2(hand, o_hand)
+    print(f"408 forwards at 60x104: reference's algorithm on the device vs its CPU run {e_ref:.3e}; HIP vs the reference's algorithm on the "
+          f"device: latents {e:.3e} hand-off {eh:.3e} (bound 2 x order noise = {2 * nf['order_out']:.3e})")
+    assert e <= 2 * nf["order_out"] and eh <= 2 * nf["order_handoff"]
+
+
+def test_t2v_chunk_50_steps_vs_gpu_semantics_fixture():
+    """HIP against the COMMITTED 408-forward fixture under the reference's native-platform scalar semantics
+    (tests/golden/chunk_t2v_tiny_50_gpu_semantics.pt, make_golden.py chunk50_gpu: the oracle -- pinned to the reference with the
+    switch off -- with nothing but the operand order of the UniPC scalar products changed).  That fixture sits 2.3e-2 from the
+    CPU-semantics one: the whole HIP-vs-CPU-reference distance of the first test is the platform's scalar rounding, not the
+    kernels.  Bound: 2 x the reference's own K/V-order noise over the same trajectory."""
+    from tests.test_pipeline_gpu import _setup
+    fx = torch.load(f"{GOLDEN}/chunk_t2v_tiny_50_gpu_semantics.pt")
+    nf = torch.load(f"{GOLDEN}/chunk_t2v_tiny_50.pt")["noise_floor"]
+    m = fx["meta"]
+    lat, hand = _hip_50()
+    e, eh = rel_l2(lat[..., ::2, ::2], fx["out_strided"]), rel_l2(hand[..., ::3, ::3], fx["handoff_strided"])
+    print(f"408 forwards at 60x104: HIP vs the GPU-semantics fixture: latents {e:.3e} hand-off {eh:.3e} (bound {2 * nf['order_out']:.3e}; "
+          f"that fixture vs the reference's CPU run: {fx['distances']['vs_cpu_semantics_out']:.3e})")
+    assert e <= 2 * nf["order_out"] and eh <= 2 * nf["order_handoff"]
 
 
 def test_t2v_chunk_2_steps_vs_reference_fixture_directly():

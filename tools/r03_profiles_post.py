@@ -59,6 +59,9 @@ if len(vals) == 2:
                "ops": n_ops, "FETCH_SIZE_KiB_per_op": vals["FETCH_SIZE"], "WRITE_SIZE_KiB_per_op": vals["WRITE_SIZE"],
                "hbm_read_bytes_per_op": rd, "hbm_write_bytes_per_op": wr, "mean_hbm_bytes_per_op": rd + wr,
                "algorithmic_bytes_per_op": algo, "ratio": (rd + wr) / algo}, open(os.path.join(d, f"{tag}_pmc_attention_hbm.json"), "w"), indent=1)
+    # bench.py reads roofline.traffic from the file THIS names (copy both into profiles/): no sorted glob
+    json.dump({"attention_traffic_file": f"{tag}_pmc_attention_hbm.json", "written_by": "tools/r03_profiles_post.py"},
+              open(os.path.join(d, "PMC_TRAFFIC.json"), "w"))
 
 # ---- MFMA busy per kernel
 fs = glob.glob(os.path.join(d, "busy", "**", "*counter_collection.csv"), recursive=True)
