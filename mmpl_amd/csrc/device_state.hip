@@ -89,7 +89,7 @@ const MmplRuntimeConfig& mmpl_config() {
     c.cross_w64 = flag("MMPL_CROSS_W64"); c.cross_no_collapse = flag("MMPL_CROSS_NO_COLLAPSE");
     c.gemm_v1 = flag("MMPL_GEMM_V1"); c.gemm_v2 = flag("MMPL_GEMM_V2"); c.gemm_direct_epilogue = flag("MMPL_GEMM_DIRECT_EPILOGUE");
     c.gemm_static_tiles = flag("MMPL_GEMM_STATIC_TILES"); c.gemm_no_sync_sweeps = flag("MMPL_GEMM_NO_SYNC_SWEEPS");
-    c.gemm_no_splitk = flag("MMPL_GEMM_NO_SPLITK");
+    c.gemm_no_splitk = flag("MMPL_GEMM_NO_SPLITK"); c.gemm_no_subtile = flag("MMPL_GEMM_NO_SUBTILE");
     c.gemm_group = num("MMPL_GEMM_GROUP", 0);
     c.gemm_pf = num("MMPL_GEMM_PF", 2);
     c.gemm_v8 = num("MMPL_GEMM_V8", -1);

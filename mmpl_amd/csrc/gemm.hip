@@ -105,34 +105,11 @@ MMPL_DEV void gemm_epilogue(const GemmArgs& g, const f32x4 (&acc)[4][4], int mw,
   }
 }
 
+// The 128 x 128 x 64 register-staged tile at (m0, n0): body of the small-problem kernel and of the sub-tile tail launch below.
 template <int EPI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel(GemmArgs g) {
-  if (g.batch > 1) {
-    g.A += (size_t)blockIdx.y * g.sA;
-    g.W += (size_t)blockIdx.y * g.sW;
-    g.C = (bf16_t*)((char*)g.C + (size_t)blockIdx.y * g.sC * (g.epi == EPI_F32_SCALE ? 4 : 2));
-  }
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+MMPL_DEV void gemm128_tile(const GemmArgs& g, char* smem, int m0, int n0) {
   char* As = smem;                   // [2][128][64] bf16, swizzled
   char* Ws = smem + 2 * TILE_BYTES;  // [2][128][64]
-
-  // ---- block -> tile mapping: XCD-aware (blocks b, b+8, ... share an L2) + grouped along M
-  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-  const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective for any nwg
-  }
-  constexpr int GROUP = 8;
-  const int per_group = GROUP * tiles_n;
-  const int gid = bid / per_group;
-  const int first_m = gid * GROUP;
-  const int gsz = min(tiles_m - first_m, GROUP);
-  const int tm = first_m + (bid % per_group) % gsz;
-  const int tn = (bid % per_group) / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
-
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
@@ -218,6 +195,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 
   gemm_epilogue<EPI>(g, acc, m0 + 64 * wm, n0 + 64 * wn, frow, fchunk);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel(GemmArgs g) {
+  if (g.batch > 1) {
+    g.A += (size_t)blockIdx.y * g.sA;
+    g.W += (size_t)blockIdx.y * g.sW;
+    g.C = (bf16_t*)((char*)g.C + (size_t)blockIdx.y * g.sC * (g.epi == EPI_F32_SCALE ? 4 : 2));
+  }
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // ---- block -> tile mapping: XCD-aware (blocks b, b+8, ... share an L2) + grouped along M
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective for any nwg
+  }
+  constexpr int GROUP = 8;
+  const int per_group = GROUP * tiles_n;
+  const int gid = bid / per_group;
+  const int first_m = gid * GROUP;
+  const int gsz = min(tiles_m - first_m, GROUP);
+  const int tm = first_m + (bid % per_group) % gsz;
+  const int tn = (bid % per_group) / gsz;
+  gemm128_tile<EPI>(g, smem, tm * BM, tn * BN);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -750,6 +753,36 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// Sub-tile launch for the partial last round of SHORT-K GEMMs (K < 4096, where the split-K launch loses to its fp32 partial exchange:
+// Wan 1.3B's qkv / o / cross-q / cross-o at 480p have 774 = 3 x 256 + 6 and 258 = 256 + 2 tiles, i.e. a whole extra round of one
+// tile per CU for 2-6 tiles).  The main launch stops at the full rounds exactly as for split-K (GemmArgs.splitk_s > 1); here every
+// leftover 256 x 256 tile of every XCD's list is computed as four 128 x 128 quadrants by the small-tile body, two blocks per CU, all
+// of them in one short round.  Same MFMA shape, operand roles and k order per accumulator as v6, same epilogue arithmetic:
+// bit-identical to the one-launch result (tests/test_kernels_gpu.py::test_gemm_subtile_tail).
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tail128_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tiles_m = (g.M + BM3 - 1) / BM3, tiles_n = (g.N + BN3 - 1) / BN3;
+  const int nwg = tiles_m * tiles_n;
+  const int my_xcd = blockIdx.x & 7, r = blockIdx.x >> 3, t_local = r >> 2, quad = r & 3;
+  // the XCD's tile list, as in gemm_bf16_v6_kernel
+  const int GROUP = g.group, per_group = GROUP * tiles_n;
+  const int rounds = g.sync_sweeps ? (tiles_m / GROUP) >> 3 : 0;
+  const int dealt = rounds * per_group, left = nwg - 8 * dealt, lq = left >> 3, lr = left & 7;
+  const int chunk_all = dealt + lq + (my_xcd < lr ? 1 : 0);
+  const int idx = chunk_all - chunk_all % g.splitk_per + t_local;
+  if (idx >= chunk_all) return;
+  int bid;
+  if (idx < dealt) bid = ((idx / per_group) * 8 + my_xcd) * per_group + idx % per_group;
+  else bid = 8 * dealt + (my_xcd < lr ? my_xcd * (lq + 1) : lr * (lq + 1) + (my_xcd - lr) * lq) + (idx - dealt);
+  const int first_m = (bid / per_group) * GROUP;
+  const int gsz = min(tiles_m - first_m, GROUP);
+  const int tm = first_m + (bid % per_group) % gsz, tn = (bid % per_group) / gsz;
+  const int m0 = tm * BM3 + 128 * (quad >> 1), n0 = tn * BN3 + 128 * (quad & 1);
+  if (m0 >= g.M || n0 >= g.N) return;
+  gemm128_tile<EPI>(g, smem, m0, n0);
+}
+
 #ifndef GEMM8_ABL
 #define GEMM8_ABL 0         // dev ablations of the v8 loop (results are garbage): 1 no LDS-DMA, 4 no fragment reads, 8 no barriers / waits
 #endif
@@ -1066,6 +1099,32 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
         else hipLaunchKernelGGL(gemm_bf16_v6_kernel<EPI>, dim3(main_tiles < n_cu ? main_tiles : n_cu), dim3(512), smem, s, g2);
       }
       hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, true>), dim3(8 * tb * sp), dim3(512), smem, s, g2);
+      return hipGetLastError();
+    }
+  }
+  // Sub-tile launch for the partial last round of short-K GEMMs (gemm_tail128_kernel): when every XCD's leftover is at most half a
+  // round of tiles, the main launch stops at the full rounds and the leftovers run as 128 x 128 quadrants (<= 2 blocks per CU, one
+  // short round) instead of a whole round of one 256 x 256 tile per CU.  Needs the tile tickets (like the split-K launch), no scratch;
+  // MMPL_GEMM_NO_SUBTILE (or MMPL_GEMM_NO_SPLITK) switches it off.
+  if (g2.tile_counter && !rc.gemm_no_splitk && !rc.gemm_no_subtile && EPI != EPI_F32_SCALE && g.K / BK4 < 64) {
+    const int tiles_n_ = (g.N + BN3 - 1) / BN3, per_group = g2.group * tiles_n_;
+    const int dealt = g2.sync_sweeps ? ((tiles_m_ / g2.group) >> 3) * per_group : 0, left = tiles - 8 * dealt;
+    int tb = 0, main_tiles = 0;
+    for (int x = 0; x < 8; ++x) {
+      const int chunk = dealt + (left >> 3) + (x < (left & 7) ? 1 : 0);
+      tb = chunk % per > tb ? chunk % per : tb;
+      main_tiles += chunk - chunk % per;
+    }
+    if (tb > 0 && 2 * tb <= per) {
+      constexpr int smem1 = 4 * TILE_BYTES;
+      if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_tail128_kernel<EPI>), smem1); e != hipSuccess) return e;
+      g2.splitk_s = 4; g2.splitk_tb = tb;                       // (the main kernel only looks at splitk_s > 1: stop at the full rounds)
+      // (tickets, like the split-K launch: the XCDs' full-round counts can differ by a whole round, which only the ticket loop absorbs)
+      if (main_tiles > 0) {
+        if (use_v8) hipLaunchKernelGGL(gemm_bf16_v8_kernel<EPI>, dim3(main_tiles < n_cu ? main_tiles : n_cu), dim3(256), 2 * STAGE4 + 2048, s, g2);
+        else hipLaunchKernelGGL(gemm_bf16_v6_kernel<EPI>, dim3(main_tiles < n_cu ? main_tiles : n_cu), dim3(512), smem, s, g2);
+      }
+      hipLaunchKernelGGL(gemm_tail128_kernel<EPI>, dim3(8 * tb * 4), dim3(256), smem1, s, g2);
       return hipGetLastError();
     }
   }

@@ -14,6 +14,7 @@
 //   MMPL_GEMM_STATIC_TILES=1     v6 with one block per tile instead of tile tickets
 //   MMPL_GEMM_NO_SYNC_SWEEPS=1   v6 with contiguous per-XCD chunks of the tile list instead of dealt M-groups
 //   MMPL_GEMM_NO_SPLITK=1        v6 without the split-K launch for the partial last round of tiles
+//   MMPL_GEMM_NO_SUBTILE=1       short-K GEMMs without the 128 x 128 sub-tile launch for the partial last round of tiles
 //   MMPL_GEMM_V8=0|1             large GEMMs never / always on gemm_bf16_v8_kernel (default: the launcher's per-shape choice)
 //   MMPL_VAE_NO_HALO=1           every VAE convolution on the plain implicit-GEMM kernel (no LDS halo tile)
 //   MMPL_VAE_NO_FUSE_NORM=1      RMS_norm + SiLU of the 96-channel layers as its own pass instead of the producing conv's epilogue
@@ -21,7 +22,7 @@
 
 struct MmplRuntimeConfig {
   bool attn_v1, attn_nosplit, attn_no_merge, cross_w64, cross_no_collapse;
-  bool gemm_v1, gemm_v2, gemm_direct_epilogue, gemm_static_tiles, gemm_no_sync_sweeps, gemm_no_splitk;
+  bool gemm_v1, gemm_v2, gemm_direct_epilogue, gemm_static_tiles, gemm_no_sync_sweeps, gemm_no_splitk, gemm_no_subtile;
   int gemm_group;      // 0 = launcher's choice
   int gemm_pf;         // k-tiles
   int gemm_v8;         // -1 = launcher's choice, 0 / 1 = never / always the one-wave-per-SIMD kernel for the main launch

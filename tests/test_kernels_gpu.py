@@ -145,6 +145,46 @@ def test_gemm_split_k_tail(lib, M, N, K, epi, split):
     assert rel_l2(out, y.to(BF)) < 2e-3 and rel_l2(out, plain) < 1e-3
 
 
+# Wan 1.3B at 480p: qkv at s1 = 43 x 18 = 774 tiles (3 rounds + 6), o / cross-q / cross-o = 258 (1 round + 2), the same at s0 = 78 tiles
+# (no full round at all), qkv at s2 = 37 x 18 = 666 (2 rounds + 154: NOT sub-tiled, the leftover is more than half a round)
+@pytest.mark.parametrize("M,N,K,epi", [(10920, 4608, 1536, 0), (10920, 1536, 1536, 3), (10920, 1536, 1536, 4), (3120, 1536, 1536, 1),
+                                       (9360, 4608, 1536, 2), (10920, 1536, 2048, 3)])
+def test_gemm_subtile_tail(lib, M, N, K, epi):
+    """Short-K GEMMs with tile tickets: the leftover tiles of the partial last round run as 128 x 128 quadrants in a second launch
+    (gemm_tail128_kernel).  Same MFMAs in the same order per accumulator, same epilogue arithmetic: bit-identical to the one-launch
+    mmpl_gemm; the ticket counters are zero again afterwards (two launches in a row)."""
+    from mmpl_amd import _lib
+    torch.manual_seed(M + N + K + epi)
+    dev = "cuda:0"
+    A = torch.randn(M, K, device=dev).to(BF)
+    W = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(BF)
+    b = (torch.randn(N, device=dev) * 0.1).to(BF)
+    res = torch.randn(M, N, device=dev).to(BF)
+    gate = torch.randn((M + 1559) // 1560, N, device=dev).to(BF)
+    ref = torch.empty(M, N, device=dev, dtype=BF)
+    _lib.check(lib.mmpl_gemm(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(ref), N, M, N, K, epi, _lib.ptr(res), N, _lib.ptr(gate), N, 1560, _sp()))
+    ctr = torch.zeros(8, dtype=torch.int32, device=dev)
+    for _ in range(2):
+        out = torch.full((M, N), float("nan"), device=dev, dtype=BF)
+        _lib.check(lib.mmpl_gemm_tickets(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(out), N, M, N, K, epi, _lib.ptr(res), N,
+                                         _lib.ptr(gate), N, 1560, _lib.ptr(ctr), _sp()))
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+        assert int(ctr.abs().sum()) == 0
+    y = A.float() @ W.float().t() + b.float()
+    y = y.to(BF).float()
+    if epi == 1:
+        y = F.gelu(y, approximate="tanh").to(BF).float()
+    elif epi == 2:
+        y = F.silu(y).to(BF).float()
+    elif epi == 3:
+        fr = torch.arange(M, device=dev) // 1560
+        y = res.float() + (y * gate.float()[fr]).to(BF).float()
+    elif epi == 4:
+        y = res.float() + y
+    assert rel_l2(out, y.to(BF)) < 2e-3
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(25200, 5120, 1024, 3), (9000, 2560, 512, 0), (4096, 5120, 5120, 1), (3120, 768, 256, 4)])
 def test_gemm_dynamic_tile_scheduling(lib, M, N, K, epi):
     """mmpl_gemm_tickets: the large-problem kernel launched once per CU, blocks drawing tiles from per-XCD tickets.  Same tiles,
