@@ -24,11 +24,13 @@
 // reference m_ref.  FAST pass: m_ref is FIXED for the whole pass and costs nothing in the loop -- it is the C operand of each score
 // tile's first MFMA (the register tile that also carries the ragged-tile mask holds -m_ref instead of 0), so S arrives already
 // shifted: one v_exp, one add and half a cvt_pk per score, and NOTHING per tile that could branch.  m_ref = 64 + the largest score of
-// the block's first KV tile (32 extra MFMAs per 256-row block before the pipeline starts; a lane's two query rows share one value).
+// the block's first FOUR KV tiles (the ones the prologue has in the ring before the pipeline starts: 128 extra MFMAs per 256-row
+// block; a lane's two query rows share one value).
 // Every p is >= 0, so the row sums only grow: one look at them after the last tile tells whether any exponential overflowed
 // (2^-100 <= l <= 2^100 is required, NaN fails) -- i.e. whether some later score beat the first tile's maximum by more than ~150
 // (log2 units; ~100 nats).  Round 3 used m_ref = 0, which holds for unit-gain synthetic weights only: with QK-norm gains x8 91 % of
-// the blocks failed it and ran twice (profiles/r04a_bench_14B_720p_heavy_tail_before_row_reference.json).  If any row of the block
+// the blocks failed it and ran twice (profiles/r04a_bench_14B_720p_heavy_tail_before_row_reference.json); with this reference 0 %
+// at gains x3, 0.5 % at x5, 26.5 % at x8 (one tile instead of four: 32.8 %; profiles/r04e_attn_ref_tiles_ab.log).  If any row of the block
 // fails, the whole block is redone by the GENERAL pass: p = exp2(S - m_ref) with a RUNNING reference (one more VALU per score), a
 // tile is accepted when every lane's partial row sum is <= 2^30, otherwise it is redone on a slow path (exact row max,
 // m_ref = max(m_ref, max), O and l rescaled through v_accvgpr moves, p recomputed).  So the result is the exact softmax up to rounding
