@@ -202,3 +202,49 @@ def test_cross_attention_padded_tail_collapse(n_valid):
     assert torch.isfinite(outs[0].float()).all() and e < 4e-3
     if n_valid >= 511:
         assert torch.equal(outs[0], outs[1])
+
+
+def test_forward_bits_do_not_depend_on_where_the_workspace_lies():
+    """A forward whose self-attention reads KV-cache slots AND its own scratch pages (write_slots = -1: the in-fill stage that appends
+    the stage's K/V to the page table, causal_fps_model.py:254-264) walks its KV tiles in an order that must not depend on whether the
+    caching allocator put the workspace below or above the KV cache: same math either way, but another tile order is another fp32
+    summation order.  (That is how the two-rank wavefront test -- fresh child processes vs the long-lived pytest process -- once
+    lost its bit-identity.)  The launcher orders pages by (allocation group, address): cache slots first, then the scratch pages.
+    Both layouts are carved from ONE buffer here, so the addresses are under the test's control."""
+    from mmpl_amd.dit import DitEngine
+    from mmpl_amd.synthetic import WAN_CONFIGS, dit_state_dict, philox_normal
+    cfg = WAN_CONFIGS["tiny"]
+    lat = (16, 24)
+    eng = DitEngine(cfg, lat[0], lat[1], "cuda:0")
+    eng.load_state_dict(dit_state_dict(cfg, seed=5))
+    S, L, d = eng.S, eng.L, eng.dim
+    ctx = philox_normal([512, cfg["text_dim"]], 31)
+    ctx[40:] = 0
+    ck, cv = eng.precompute_context(ctx.cuda())
+    n_slots, nF = 15, 6
+    kv_bytes = L * n_slots * S * d * 2
+    ws_bytes = eng.workspace(nF).numel()
+    pad = lambda n: (n + 4095) // 4096 * 4096
+    arena = torch.zeros(2 * pad(kv_bytes) + pad(ws_bytes) + 4096, dtype=torch.uint8, device="cuda:0")
+    fill_k = philox_normal([L, n_slots * S, d], 41).to(BF).cuda()
+    fill_v = philox_normal([L, n_slots * S, d], 42).to(BF).cuda()
+    x = philox_normal([nF, 16, lat[0], lat[1]], 43).to(BF).cuda()
+    t = torch.full([nF], 500.0, dtype=torch.float32, device="cuda:0")
+    frames, visible = [11, 12, 13, 14, 15, 16], [0, 1, 2, 3, 4, 5, 6, 8, 9]
+    outs = []
+    for ws_first in (False, True):
+        off = 0
+        parts = {}
+        for name, nb in ((("ws", ws_bytes), ("k", kv_bytes), ("v", kv_bytes)) if ws_first else (("k", kv_bytes), ("v", kv_bytes), ("ws", ws_bytes))):
+            parts[name] = arena[off:off + nb]
+            off += pad(nb)
+        kc = parts["k"].view(BF).view(L, n_slots * S, d)
+        vc = parts["v"].view(BF).view(L, n_slots * S, d)
+        kc.copy_(fill_k)
+        vc.copy_(fill_v)
+        assert (parts["ws"].data_ptr() < kc.data_ptr()) == ws_first
+        y = eng.forward(x, t, frames, [-1] * nF, visible, kc, vc, ck, cv, workspace=parts["ws"])
+        torch.cuda.synchronize()
+        outs.append(y.clone())
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1])
