@@ -226,3 +226,44 @@ def test_i2v_model_type_production_dims():
     e = rel_l2(y, yo)
     print(f"i2v model type, dim 1536 / 480p / 4 layers: rel_l2(HIP, oracle on device) = {e:.3e}")
     assert torch.isfinite(y.float()).all() and e < TOL
+
+
+def test_full_width_one_layer_vs_cpu_oracle_directly():
+    """No device-evaluated hop: Wan2.1-14B WIDTH (dim 5120, 40 heads, ffn 13824) at the 720p geometry, ONE layer, stage s0 (2 query
+    frames over 2) and then the anchor stage s1 (7 query frames = 25 200 rows over 9 frames = 32 400 keys) with the live KV cache --
+    the large-problem GEMM kernels on the real block shapes, the 64-rows-per-wave attention with 40 heads, 57-tile pages and its
+    split-KV tail, the fused epilogues -- against the pinned CPU oracle itself (oracle/wan_dit_ref.py on the host CPU; ~1 min on the
+    GPU box's 128 threads).  Bound: 1e-2 per forward (the same comparison on the tiny model measures 2.5e-3)."""
+    from mmpl_amd.dit import DitEngine
+    from mmpl_amd.synthetic import WAN_CONFIGS, dit_state_dict, philox_normal
+    from oracle import stage_ref
+    from oracle import wan_dit_ref as W
+    cfg = dict(WAN_CONFIGS["14B"])
+    cfg["num_layers"] = 1
+    lat = (90, 160)
+    sd = dit_state_dict(cfg, seed=33)
+    eng = DitEngine(cfg, lat[0], lat[1], "cuda:0")
+    eng.load_state_dict(sd)
+    ocfg = W.DitCfg(**cfg)
+    S = eng.S
+    ctx = philox_normal([512, cfg["text_dim"]], 34)
+    ctx[77:] = 0
+    noise = philox_normal([21, 16, lat[0], lat[1]], 35)
+    kc, vc = eng.new_kv_cache(15)
+    ck, cv = eng.precompute_context(ctx.cuda())
+    okv = W.new_kv_cache(ocfg, 15, S)
+    ocross = [None]
+    vis = stage_ref.VisIndex()
+    for si, frames in enumerate(stage_ref.stage_frames(stage_ref.T2V_CLEAN_STEPS)[:2]):
+        vis.on_forward(frames)
+        order = vis.slots()
+        x = noise[frames].contiguous()
+        t = torch.full([len(frames)], (999.0, 750.0)[si], dtype=torch.float32)
+        ws = stage_ref.write_slots_for(frames)
+        y = eng.forward(x.cuda(), t.cuda(), frames, ws, order, kc, vc, ck, cv).cpu()
+        yo = W.dit_forward(sd, ocfg, x.permute(1, 0, 2, 3), t.view(1, -1), ctx, okv, ocross, frames, ws, order).permute(1, 0, 2, 3)
+        e = rel_l2(y, yo)
+        print(f"14B width, 1 layer, 720p, stage s{si} (Lq {len(frames) * S}, Lkv {len(order) * S}): rel_l2(HIP, CPU oracle) = {e:.3e}")
+        assert torch.isfinite(y.float()).all() and e < 1e-2
+        slot = [w for w in ws if w >= 0][0]
+        assert rel_l2(kc[0, slot * S:(slot + 1) * S].cpu(), okv[0]["k"][0, slot * S:(slot + 1) * S].reshape(S, -1)) < 1e-2
