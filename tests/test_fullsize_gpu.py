@@ -233,7 +233,7 @@ def test_full_width_one_layer_vs_cpu_oracle_directly():
     frames over 2) and then the anchor stage s1 (7 query frames = 25 200 rows over 9 frames = 32 400 keys) with the live KV cache --
     the large-problem GEMM kernels on the real block shapes, the 64-rows-per-wave attention with 40 heads, 57-tile pages and its
     split-KV tail, the fused epilogues -- against the pinned CPU oracle itself (oracle/wan_dit_ref.py on the host CPU; ~1 min on the
-    GPU box's 128 threads).  Bound: 1e-2 per forward (the same comparison on the tiny model measures 2.5e-3)."""
+    GPU box's 128 threads).  Measured 4.4e-3 / 4.3e-3 (profiles/r04h_full_width_one_layer_vs_cpu_oracle.log); bound 8e-3 per forward."""
     from mmpl_amd.dit import DitEngine
     from mmpl_amd.synthetic import WAN_CONFIGS, dit_state_dict, philox_normal
     from oracle import stage_ref
@@ -264,6 +264,6 @@ def test_full_width_one_layer_vs_cpu_oracle_directly():
         yo = W.dit_forward(sd, ocfg, x.permute(1, 0, 2, 3), t.view(1, -1), ctx, okv, ocross, frames, ws, order).permute(1, 0, 2, 3)
         e = rel_l2(y, yo)
         print(f"14B width, 1 layer, 720p, stage s{si} (Lq {len(frames) * S}, Lkv {len(order) * S}): rel_l2(HIP, CPU oracle) = {e:.3e}")
-        assert torch.isfinite(y.float()).all() and e < 1e-2
+        assert torch.isfinite(y.float()).all() and e < 8e-3
         slot = [w for w in ws if w >= 0][0]
         assert rel_l2(kc[0, slot * S:(slot + 1) * S].cpu(), okv[0]["k"][0, slot * S:(slot + 1) * S].reshape(S, -1)) < 1e-2
