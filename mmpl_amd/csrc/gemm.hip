@@ -1040,6 +1040,7 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
   if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v6_kernel<EPI>), smem); e != hipSuccess) return e;
   if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v6_kernel<EPI, true>), smem); e != hipSuccess) return e;
   if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v8_kernel<EPI>), 2 * STAGE4 + 2048); e != hipSuccess) return e;
+  if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_tail128_kernel<EPI>), 4 * TILE_BYTES); e != hipSuccess) return e;
   // main-launch kernel: v8 (one wave per SIMD, 128 x 128 per wave) or v6 (two, 128 x 64).  MMPL_GEMM_V8 = 1 / 0 forces it.
   const int env_v8 = mmpl_config().gemm_v8;
   const bool use_v8 = env_v8 >= 0 ? env_v8 != 0 : g.N >= 8192;       // the wide GEMMs (qkv, ffn0): profiles/r04c_gemm_v8_*.log
@@ -1117,7 +1118,6 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
     }
     if (tb > 0 && 2 * tb <= per) {
       constexpr int smem1 = 4 * TILE_BYTES;
-      if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_tail128_kernel<EPI>), smem1); e != hipSuccess) return e;
       g2.splitk_s = 4; g2.splitk_tb = tb;                       // (the main kernel only looks at splitk_s > 1: stop at the full rounds)
       // (tickets, like the split-K launch: the XCDs' full-round counts can differ by a whole round, which only the ticket loop absorbs)
       if (main_tiles > 0) {
