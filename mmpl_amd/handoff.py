@@ -175,7 +175,23 @@ class ChunkHandoff:
         if not self.handshake or self.owner(chunk) == self.rank or chunk in self._ready_req:
             return
         buf = torch.zeros(1, dtype=torch.int64)
-        self._ready_req[chunk] = (self.dist.irecv(buf, self._g(self.owner(chunk)), group=self._ctl, tag=_READY_TAG + chunk), buf)
+        req = self.dist.irecv(buf, self._g(self.owner(chunk)), group=self._ctl, tag=_READY_TAG + chunk)
+        # A gloo receive's Work.is_completed() stays False until somebody WAITS on it, however long ago the message landed
+        # (measured: tools-free probe in profiles/NOTEBOOK_r04.md section J) -- polling it would defer every hand-off to the blocking
+        # drain at the end of the producer's chunk and serialise the wavefront.  So a daemon thread does the waiting (Work.wait()
+        # releases the GIL) and an Event carries the news to the non-blocking checks at the sink and at the stage boundaries.
+        import threading
+        arrived, failed = threading.Event(), []
+
+        def waiter():
+            try:
+                req.wait()
+            except Exception as e:                             # timeout / peer gone: surfaces at the next readiness check
+                failed.append(e)
+            finally:
+                arrived.set()
+        threading.Thread(target=waiter, name=f"mmpl-ready-{chunk}", daemon=True).start()
+        self._ready_req[chunk] = (req, buf, arrived, failed)
 
     def announce_ready(self, chunk: int) -> None:
         """Consumer of `chunk`: tell the producer of chunk - 1 that the recv is about to be posted."""
@@ -191,11 +207,12 @@ class ChunkHandoff:
             return True
         if chunk not in self._ready_req:
             self.expect_ready(chunk)
-        req, _ = self._ready_req[chunk]
+        _, _, arrived, failed = self._ready_req[chunk]
         if block:
-            req.wait()
-            return True
-        return bool(req.is_completed())
+            arrived.wait()
+        if arrived.is_set() and failed:
+            raise RuntimeError(f"hand-off: waiting for the consumer of chunk {chunk} to announce itself failed: {failed[0]}")
+        return arrived.is_set()
 
     def _issue(self, chunk: int, hdr: torch.Tensor, payload: torch.Tensor) -> None:
         import time

@@ -61,6 +61,9 @@ def test_measured_wavefront_two_lanes():
     assert len(r["chunk_s"]) == 4 and len(r["stagger_s"]) == 3 and all(s > 0 for s in r["stagger_s"])
     # chunk c + 1 cannot start before chunk c's anchor stage is done (the dependency is real)
     assert all(st >= a - 0.05 for st, a in zip(r["stagger_s"], r["anchor_done_after_s"]))
+    # ... and it IS a wavefront: chunk c + 1 starts when chunk c's anchors arrive, not when chunk c has finished (a hand-off that only
+    # left at the end of the producer's chunk showed up here as stagger == chunk time)
+    assert all(st < 0.9 * cs for st, cs in zip(r["stagger_s"], r["chunk_s"])), (r["stagger_s"], r["chunk_s"])
     assert set(r["rank_busy_fraction"]) == {"0", "1"} and all(0 < v <= 1.0 for v in r["rank_busy_fraction"].values())
     assert set(r["handoff_latency_s"]) == {"1", "2", "3"} and all(0 <= v < 30 for v in r["handoff_latency_s"].values())
     assert "not_the_metric" in r and "functional_only" in r          # 3 sampling steps, shared GPU

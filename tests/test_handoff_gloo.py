@@ -95,8 +95,8 @@ def _hs_worker(rank, world, port, out_path):
 
     def spy(chunk, hdr, payload):
         # the invariant the handshake exists for: a send is only ever issued against an announced consumer
-        req, _ = ho._ready_req[chunk + 1]
-        ev.append(("issue", chunk, bool(req.is_completed())))
+        arrived = ho._ready_req[chunk + 1][2]
+        ev.append(("issue", chunk, bool(arrived.is_set()), time.time()))
         issue(chunk, hdr, payload)
     ho._issue = spy
 
@@ -106,7 +106,7 @@ def _hs_worker(rank, world, port, out_path):
             base = base + initial.float().mean().to(torch.bfloat16)
         time.sleep(0.2)                      # "anchor stage"
         sink(base)
-        ev.append(("sink", c, len(ho._deferred)))
+        ev.append(("sink", c, len(ho._deferred), time.time()))
         for _ in range(6 if rank == 0 else 1):     # "in-fill stages", a poll at every stage boundary
             time.sleep(0.25)
             ho.poll()
@@ -131,6 +131,14 @@ def test_ready_handshake_defers_sends_until_the_consumer_announced(tmp_path):
     # part, in any case before rank 0's next chunk (not only by the blocking drain at the end of the wavefront)
     kinds = [(e[0], e[1]) for e in r0["ev"]]
     assert kinds.index(("issue", 0)) < kinds.index(("sink", 2)) and kinds.index(("issue", 2)) < kinds.index(("sink", 4))
+    # ... and NOT by the drain: rank 1 is idle and has announced long before rank 0's sinks, so rank 0's hand-offs must leave AT the
+    # sink (or the first poll, 0.25 s later), not 1.5 s later when its chunk ends.  (A gloo Work's is_completed() never turns true
+    # without a wait: polling it deferred every hand-off to the end of the producer's chunk and serialised the wavefront -- which
+    # bench.py --wavefront-chunks showed as stagger == chunk time.)
+    t_of = {(e[0], e[1]): e[3] for e in r0["ev"]}
+    for c in (0, 2):
+        assert t_of[("issue", c)] - t_of[("sink", c)] < 0.6, (c, t_of[("issue", c)] - t_of[("sink", c)])
+    assert all(e[2] == 0 for e in r0["ev"] if e[0] == "sink"), r0["ev"]                  # nothing of rank 0's was ever deferred
     # stamps of every hand-off on the consumer side: sink (producer clock, same host) <= recv done, ready announced before recv done
     for r, chunks in ((r0, (2, 4)), (r1, (1, 3))):
         for c in chunks:
