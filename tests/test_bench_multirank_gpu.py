@@ -73,3 +73,14 @@ def test_measured_wavefront_one_rank_is_the_sequential_chain():
     r = _wavefront(1, [])
     assert r["n_gpus"] == 1 and r["lanes"] == 1 and "sequential chain" in r["config"]["parallelism"]
     assert sum(r["chunk_s"]) <= r["wall_s"] * 1.001 and r["rank_busy_fraction"]["0"] > 0.5
+
+
+def test_measured_wavefront_two_lanes_of_cfg_pairs():
+    """The layout an 8-GPU run uses (N >= 4: N / 2 chunk lanes x (cond, uncond) rank pairs), here 4 ranks on one GPU over gloo: the
+    hand-off runs between the lane heads (the cond ranks), each pair exchanges its two flow predictions per step, and the wavefront
+    is measured the same way."""
+    r = _wavefront(4, ["--cfg-split"])
+    assert r["n_gpus"] == 4 and r["chunks"] == 4 and r["lanes"] == 2 and "measured wavefront" in r["config"]["parallelism"]
+    assert abs(r["value"] - 21.0 * 4 / r["wall_s"]) < 1e-9
+    assert len(r["stagger_s"]) == 3 and all(st >= a - 0.05 for st, a in zip(r["stagger_s"], r["anchor_done_after_s"]))
+    assert all(st < 0.9 * cs for st, cs in zip(r["stagger_s"], r["chunk_s"])), (r["stagger_s"], r["chunk_s"])
