@@ -841,13 +841,16 @@ struct G8 {
 
 // gap placement of one k-tile (dev sweep: -DGEMM8_...)
 #ifndef GEMM8_BAR1
-#define GEMM8_BAR1 36        // phase 1: lgkmcnt(0) + barrier (the 16 second-half reads sit in gaps 0, 2, .. 30)
+#define GEMM8_BAR1 36        // phase 1: lgkmcnt(0) + barrier (behind the 16 second-half reads: gaps 0, RD, .. 15 RD)
 #endif
 #ifndef GEMM8_DMAS
 #define GEMM8_DMAS 3         // gaps between DMA pieces (never back to back: the four waves run in step and the CU has one address path)
 #endif
 #ifndef GEMM8_BAR2
-#define GEMM8_BAR2 30        // phase 2: vmcnt + barrier, then the next tile's first-half reads in gaps BAR2 + 2, + 4, ..
+#define GEMM8_BAR2 30        // phase 2: vmcnt + barrier, then the next tile's first-half reads in gaps BAR2 + RD, + 2 RD, ..
+#endif
+#ifndef GEMM8_RD
+#define GEMM8_RD 2           // gaps between fragment reads (16 per phase): phase 1 in gaps 0, RD, 2 RD ..; phase 2 in gaps BAR2 + RD, BAR2 + 2 RD ..
 #endif
 #ifndef GEMM8_PF
 #define GEMM8_PF 0           // 1: two L2 prefetch ops per wave and k-tile behind the DMA pieces (G8::prefetch).  Measured on v8
@@ -856,12 +859,12 @@ struct G8 {
 template <int S, bool ISSUE, bool NEXT, bool FIRST = false> MMPL_DEV void gemm8_tile(G8& k) {
   constexpr int D1 = GEMM8_BAR1 + 2;                                   // first DMA gap of phase 1
   constexpr int N1 = (64 - D1 + GEMM8_DMAS - 1) / GEMM8_DMAS;          // pieces issued in phase 1
-  static_assert(N1 >= 0 && N1 <= 16 && (16 - N1) * GEMM8_DMAS + 1 < GEMM8_BAR2 && GEMM8_BAR2 + 2 + 2 * 15 < 64, "placement");
+  static_assert(N1 >= 0 && N1 <= 16 && (16 - N1) * GEMM8_DMAS + 1 < GEMM8_BAR2 && GEMM8_BAR2 + GEMM8_RD * 16 < 64 && GEMM8_RD * 15 < GEMM8_BAR1, "placement");
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // this tile's first-half fragments
   sfor<64>([&k](auto gi) {
     constexpr int g = decltype(gi)::value;
     k.template mfma<0, g / 8, g % 8, FIRST>();
-    if constexpr ((g & 1) == 0 && g < 32) k.template lds<S, 1, g / 2>();
+    if constexpr (g % GEMM8_RD == 0 && g / GEMM8_RD < 16) k.template lds<S, 1, g / GEMM8_RD>();
     if constexpr (g == GEMM8_BAR1 && !(GEMM8_ABL & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if constexpr (ISSUE && g >= D1 && (g - D1) % GEMM8_DMAS == 0) k.template dma<S, (g - D1) / GEMM8_DMAS>();
   });
@@ -875,7 +878,8 @@ template <int S, bool ISSUE, bool NEXT, bool FIRST = false> MMPL_DEV void gemm8_
       if constexpr (ISSUE) asm volatile("s_waitcnt vmcnt(%c0)\n\ts_barrier" ::"i"(GEMM8_PF ? 20 : 16) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    if constexpr (NEXT && g > GEMM8_BAR2 && ((g - GEMM8_BAR2) & 1) == 0 && (g - GEMM8_BAR2) / 2 <= 16) k.template lds<S ^ 1, 0, (g - GEMM8_BAR2) / 2 - 1>();
+    if constexpr (NEXT && g > GEMM8_BAR2 && (g - GEMM8_BAR2) % GEMM8_RD == 0 && (g - GEMM8_BAR2) / GEMM8_RD <= 16)
+      k.template lds<S ^ 1, 0, (g - GEMM8_BAR2) / GEMM8_RD - 1>();
   });
   if constexpr (ISSUE) { k.a_k += BK4; k.w_k += BK4; }
 }
@@ -903,6 +907,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int frow = lane & 15, fchunk = lane >> 4;
+  [[maybe_unused]] unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;      // dev: -DGEMM6_TIMING=1 (as gemm_bf16_v6_kernel)
+  if constexpr (GEMM6_TIMING) tk0 = __builtin_readcyclecounter();
   asm volatile("s_nop 0" ::: MMPL_ALL_AGPRS);
 
   G8 k;
@@ -981,6 +987,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     sfor<16>([&k](auto r) { k.template lds<0, 0, decltype(r)::value>(); });
 
+    if constexpr (GEMM6_TIMING) tk1 = __builtin_readcyclecounter();
     int t = 0;
     if (nt >= 4) {
       gemm8_tile<0, true, true, true>(k);
@@ -1005,6 +1012,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // every wave is past the last tile's phase-1 barrier: nobody reads the ring any more, the epilogue stages through it.
     // (the MFMA results need their passes before a VALU instruction may read the accumulator file)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    if constexpr (GEMM6_TIMING) tk2 = __builtin_readcyclecounter();
 
     // ---- epilogue: v6's, on the two 128 x 64 halves of the wave's sub-tile.  Its lane-dependent addresses are derived from an
     // OPAQUE copy of the lane id defined here: otherwise hipcc hoists them above the k loop and, short of VGPRs there, parks them
@@ -1029,6 +1037,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         gemm_epilogue<EPI>(g, acc[1], mw + 64, nw, frow_e, fchunk_e);
       }
     });
+    if constexpr (GEMM6_TIMING) {      // per-wave { prologue, k loop, epilogue } shader cycles over the output (tools/bench_kernels.py gemmphases)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      tk3 = __builtin_readcyclecounter();
+      __syncthreads();
+      if (lane == 0) {
+        float* tp = reinterpret_cast<float*>(g.C) + (blockIdx.x * 4 + wave) * 4;
+        tp[0] = (float)(tk1 - tk0);
+        tp[1] = (float)(tk2 - tk1);
+        tp[2] = (float)(tk3 - tk2);
+        tp[3] = (float)(2 * nt);
+      }
+    }
     if (!persistent) return;
     __syncthreads();                 // the ring (and s_ticket) are free again
   }

@@ -100,7 +100,7 @@ def bench_gemm_ref(iters):
 
 def gemm_phases(epi=3):
     """needs a -DGEMM6_TIMING=1 build (tools/gemm6_phases2.sh): per-wave { prologue, k loop, epilogue } cycles written over the output"""
-    M, N, K = 25200, 5120, 5120
+    M, N, K = (int(v) for v in os.environ.get("BENCH_PHASE_SHAPE", "25200:5120:5120").split(":"))
     A = torch.randn(M, K, device=dev).to(BF)
     W = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(BF)
     b = torch.randn(N, device=dev).to(BF)
@@ -114,7 +114,7 @@ def gemm_phases(epi=3):
     nblk = ((M + 255) // 256) * (N // 256)
     t = Cc.view(-1).view(torch.float32)[: nblk * 16].view(-1, 4).double()
     t = t[t[:, 3] == K // 32]
-    print(f"gemmphases epi={epi}: waves {len(t)}  prologue {t[:, 0].mean().item():.0f}  loop {t[:, 1].mean().item():.0f} "
+    print(f"gemmphases {M}x{N}x{K} epi={epi}: waves {len(t)}  prologue {t[:, 0].mean().item():.0f}  loop {t[:, 1].mean().item():.0f} "
           f"({t[:, 1].mean().item() / (K // 32) / 32:.2f} per MFMA; p5 {t[:, 1].quantile(0.05).item():.0f} p50 {t[:, 1].quantile(0.5).item():.0f} "
           f"p95 {t[:, 1].quantile(0.95).item():.0f})  epilogue {t[:, 2].mean().item():.0f} (max {t[:, 2].max().item():.0f}) cycles", flush=True)
 
