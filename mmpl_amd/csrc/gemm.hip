@@ -852,6 +852,9 @@ struct G8 {
 #ifndef GEMM8_RD
 #define GEMM8_RD 2           // gaps between fragment reads (16 per phase): phase 1 in gaps 0, RD, 2 RD ..; phase 2 in gaps BAR2 + RD, BAR2 + 2 RD ..
 #endif
+#ifndef GEMM8_FINEWAIT
+#define GEMM8_FINEWAIT 1     // 1: the loop-top wait for the first-half fragments is split per activation fragment (counted lgkmcnt) instead of
+#endif                       //    one lgkmcnt(0): only the 8 weight fragments + the first activation fragment gate the first MFMA
 #ifndef GEMM8_PF
 #define GEMM8_PF 0           // 1: two L2 prefetch ops per wave and k-tile behind the DMA pieces (G8::prefetch).  Measured on v8
 #endif                       // (profiles/r04d_gemm_v8_sweep.log): ffn2 +4 % (= v6's level), but qkv -1 %, ffn0 -4 %: off, ffn2 stays on v6
@@ -860,9 +863,18 @@ template <int S, bool ISSUE, bool NEXT, bool FIRST = false> MMPL_DEV void gemm8_
   constexpr int D1 = GEMM8_BAR1 + 2;                                   // first DMA gap of phase 1
   constexpr int N1 = (64 - D1 + GEMM8_DMAS - 1) / GEMM8_DMAS;          // pieces issued in phase 1
   static_assert(N1 >= 0 && N1 <= 16 && (16 - N1) * GEMM8_DMAS + 1 < GEMM8_BAR2 && GEMM8_BAR2 + GEMM8_RD * 16 < 64 && GEMM8_RD * 15 < GEMM8_BAR1, "placement");
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // this tile's first-half fragments
+  // this tile's first-half fragments, read at the end of the previous tile in the order w0..w7, a0..a7 (LDS returns in order): MFMA row i
+  // needs everything up to a_i, i.e. at most 7 - i of those reads may still be outstanding -- plus the second-half reads this phase has
+  // issued by then (the counter is 4 bits: 15 = "all of the old ones", since the newest 16 are then the new reads)
+  if constexpr (GEMM8_FINEWAIT) asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+  else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   sfor<64>([&k](auto gi) {
     constexpr int g = decltype(gi)::value;
+    if constexpr (GEMM8_FINEWAIT && g % 8 == 0 && g > 0) {
+      constexpr int i = g / 8, n_new = (g + GEMM8_RD - 1) / GEMM8_RD < 16 ? (g + GEMM8_RD - 1) / GEMM8_RD : 16;
+      constexpr int n = 7 - i + n_new < 15 ? 7 - i + n_new : 15;
+      asm volatile("s_waitcnt lgkmcnt(%c0)" ::"i"(n) : "memory");
+    }
     k.template mfma<0, g / 8, g % 8, FIRST>();
     if constexpr (g % GEMM8_RD == 0 && g / GEMM8_RD < 16) k.template lds<S, 1, g / GEMM8_RD>();
     if constexpr (g == GEMM8_BAR1 && !(GEMM8_ABL & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
