@@ -53,7 +53,10 @@ constexpr int QB = 256, KVB = 64, TILE = KVB * 256, RING = 4;         // K ring 
 constexpr int W64_SMEM = 2 * RING * TILE + 64;     // + the block's redo flag
 constexpr float BOUND_GEN = 1073741824.f;                              // 2^30: a GENERAL tile's partial row sums
 constexpr float FAST_L_MIN = 7.888609e-31f, FAST_L_MAX = 1.2676506e30f;       // 2^-100, 2^100: a FAST pass's final row sums
-constexpr float FAST_REF_OFFSET = 64.f;       // FAST pass: m_ref = (largest score of the block's first FAST_REF_TILES KV tiles) + this
+#ifndef W64_REF_OFFSET
+#define W64_REF_OFFSET 64
+#endif
+constexpr float FAST_REF_OFFSET = W64_REF_OFFSET;   // FAST pass: m_ref = (largest score of the block's first FAST_REF_TILES KV tiles) + this
 #ifndef W64_REF_TILES
 #define W64_REF_TILES 4
 #endif
