@@ -79,7 +79,10 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int n_fra
                      size_t workspace_bytes, mmpl_stream_t stream);
 
 /* attention() seam (wan/modules/attention.py:139-185) over paged K/V.  q/o: row r, head h at base + r*ld + h*128.
- * k_pages/v_pages: host arrays of n_pages dev pointers, each page = page_rows rows of stride ldk/ldv. */
+ * k_pages/v_pages: host arrays of n_pages dev pointers, each page = page_rows rows of stride ldk/ldv.
+ * Softmax does not depend on the order of the keys, the fp32 accumulation does: the 64-rows-per-wave kernel visits the pages in
+ * ADDRESS order (back-to-back pages are merged), so a result is bit-reproducible for a given relative placement of the pages.
+ * (mmpl_dit_forward keeps its two allocations -- cache slots, scratch pages -- apart, so ITS bits do not depend on placement.) */
 int mmpl_attn_fwd(const void* q, int ldq, void* o, int ldo, const void* const* k_pages, const void* const* v_pages,
                   int ldk, int ldv, int n_pages, int page_rows, int Lq, int num_heads, float softmax_scale,
                   mmpl_stream_t stream);
