@@ -753,13 +753,92 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// The same 128 x 128 x 64 tile for the sub-tile tail launch, fed by a 4-stage LDS-DMA ring (128 KiB: a tail block has its CU to itself).
+// The register-staged body above keeps ONE k-tile in flight; run by the handful of tail blocks on an otherwise idle chip it is pure
+// latency (24 k-steps of ~1.2 us: a round of 128 x 128 quadrants took 0.8 of a full round of 256 x 256 tiles, profiles/r04f_*).  Here
+// three k-tiles are in flight behind the one being multiplied.  Same MFMA shape, operand roles, k order and epilogue: same bits.
+template <int EPI>
+MMPL_DEV void gemm128_ring_tile(const GemmArgs& g, char* smem, int m0, int n0) {
+  constexpr int NST = 4, STG = 2 * TILE_BYTES;                  // stage = A rows [0, 16 KiB) + W rows [16 KiB, 32 KiB)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  // piece p of an operand tile = rows 8p .. 8p + 7 (1 KiB, lane-linear in LDS: row 8p + (lane >> 3), chunk position lane & 7, which holds
+  // logical chunk (lane & 7) ^ (row & 7)); wave w issues pieces 4q + w, q = 0..3, of A and of W
+  const int prow = lane >> 3, lc = ((lane & 7) ^ (prow & 7)) << 3;
+  uint32_t a_vo[4], w_vo[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int p = 4 * q + wave;
+    a_vo[q] = (uint32_t)(min(m0 + 8 * p + prow, g.M - 1) * g.lda + lc) * 2u;
+    w_vo[q] = (uint32_t)(min(n0 + 8 * p + prow, g.N - 1) * g.ldw + lc) * 2u;
+  }
+  const int nt = g.K / BK;
+  auto issue = [&](int t) {                                      // all 8 pieces of k-tile t into stage t & 3
+    char* st = smem + (t & (NST - 1)) * STG;
+    const bf16_t* ak = g.A + (size_t)t * BK;
+    const bf16_t* wk = g.W + (size_t)t * BK;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) glds16s(ak, a_vo[q], st + (4 * q + wave) * 1024);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) glds16s(wk, w_vo[q], st + TILE_BYTES + (4 * q + wave) * 1024);
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fchunk = lane >> 4;
+  int a_off[4], w_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ar = 64 * wm + 16 * i + frow, wr = 64 * wn + 16 * i + frow;
+    a_off[i] = ar * 128 + ((fchunk ^ (ar & 7)) << 4);
+    w_off[i] = TILE_BYTES + wr * 128 + ((fchunk ^ (wr & 7)) << 4);
+  }
+  const int pre = nt < NST - 1 ? nt : NST - 1;
+  for (int t = 0; t < pre; ++t) issue(t);
+  // in flight per wave, oldest first: 8 pieces per k-tile.  k-tile t has landed when at most 8 x (tiles issued after it) are outstanding
+  if (pre >= 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if (pre == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll 1
+  for (int t = 0; t < nt; ++t) {
+    if (t + NST - 1 < nt) issue(t + NST - 1);                    // into the stage k-tile t - 1 left (everybody is past it: barrier below)
+    const char* st = smem + (t & (NST - 1)) * STG;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8*>(st + (a_off[i] ^ (ks << 6)));
+        wf[i] = *reinterpret_cast<const bf16x8*>(st + (w_off[i] ^ (ks << 6)));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    // k-tile t + 1 must have landed: tiles t + 2 and t + 3 (those that exist) may still be on their way
+    const int later = (t + 3 < nt ? 1 : 0) + (t + 2 < nt ? 1 : 0);
+    if (later == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  gemm_epilogue<EPI>(g, acc, m0 + 64 * wm, n0 + 64 * wn, frow, fchunk);
+}
+
 // Sub-tile launch for the partial last round of SHORT-K GEMMs (K < 4096, where the split-K launch loses to its fp32 partial exchange:
 // Wan 1.3B's qkv / o / cross-q / cross-o at 480p have 774 = 3 x 256 + 6 and 258 = 256 + 2 tiles, i.e. a whole extra round of one
 // tile per CU for 2-6 tiles).  The main launch stops at the full rounds exactly as for split-K (GemmArgs.splitk_s > 1); here every
-// leftover 256 x 256 tile of every XCD's list is computed as four 128 x 128 quadrants by the small-tile body, two blocks per CU, all
-// of them in one short round.  Same MFMA shape, operand roles and k order per accumulator as v6, same epilogue arithmetic:
+// leftover 256 x 256 tile of every XCD's list is computed as four 128 x 128 quadrants (gemm128_ring_tile), one block per CU, all of
+// them in one short round.  Same MFMA shape, operand roles and k order per accumulator as v6, same epilogue arithmetic:
 // bit-identical to the one-launch result (tests/test_kernels_gpu.py::test_gemm_subtile_tail).
-template <int EPI>
+// RING: the 4-stage DMA-ring body (128 KiB of LDS, one block per CU: leftovers that fit one round that way, <= 8 tiles per XCD);
+// else the register-staged body (64 KiB, two blocks per CU: up to 16 tiles per XCD, e.g. the 78-tile GEMMs that have no full round).
+template <int EPI, bool RING>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tail128_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_m = (g.M + BM3 - 1) / BM3, tiles_n = (g.N + BN3 - 1) / BN3;
@@ -780,7 +859,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int tm = first_m + (bid % per_group) % gsz, tn = (bid % per_group) / gsz;
   const int m0 = tm * BM3 + 128 * (quad >> 1), n0 = tn * BN3 + 128 * (quad & 1);
   if (m0 >= g.M || n0 >= g.N) return;
-  gemm128_tile<EPI>(g, smem, m0, n0);
+  if constexpr (RING) gemm128_ring_tile<EPI>(g, smem, m0, n0);
+  else gemm128_tile<EPI>(g, smem, m0, n0);
 }
 
 #ifndef GEMM8_ABL
@@ -1072,7 +1152,8 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
   if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v6_kernel<EPI>), smem); e != hipSuccess) return e;
   if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v6_kernel<EPI, true>), smem); e != hipSuccess) return e;
   if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v8_kernel<EPI>), 2 * STAGE4 + 2048); e != hipSuccess) return e;
-  if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_tail128_kernel<EPI>), 4 * TILE_BYTES); e != hipSuccess) return e;
+  if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_tail128_kernel<EPI, true>), 8 * TILE_BYTES); e != hipSuccess) return e;
+  if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_tail128_kernel<EPI, false>), 4 * TILE_BYTES); e != hipSuccess) return e;
   // main-launch kernel: v8 (one wave per SIMD, 128 x 128 per wave) or v6 (two, 128 x 64).  MMPL_GEMM_V8 = 1 / 0 forces it.
   const int env_v8 = mmpl_config().gemm_v8;
   const bool use_v8 = env_v8 >= 0 ? env_v8 != 0 : g.N >= 8192;       // the wide GEMMs (qkv, ffn0): profiles/r04c_gemm_v8_*.log
@@ -1136,7 +1217,7 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
     }
   }
   // Sub-tile launch for the partial last round of short-K GEMMs (gemm_tail128_kernel): when every XCD's leftover is at most half a
-  // round of tiles, the main launch stops at the full rounds and the leftovers run as 128 x 128 quadrants (<= 2 blocks per CU, one
+  // round of tiles, the main launch stops at the full rounds and the leftovers run as 128 x 128 quadrants (a 4-stage DMA-ring body, one
   // short round) instead of a whole round of one 256 x 256 tile per CU.  Needs the tile tickets (like the split-K launch), no scratch;
   // MMPL_GEMM_NO_SUBTILE (or MMPL_GEMM_NO_SPLITK) switches it off.
   if (g2.tile_counter && !rc.gemm_no_splitk && !rc.gemm_no_subtile && EPI != EPI_F32_SCALE && g.K / BK4 < 64) {
@@ -1149,14 +1230,14 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
       main_tiles += chunk - chunk % per;
     }
     if (tb > 0 && 2 * tb <= per) {
-      constexpr int smem1 = 4 * TILE_BYTES;
       g2.splitk_s = 4; g2.splitk_tb = tb;                       // (the main kernel only looks at splitk_s > 1: stop at the full rounds)
       // (tickets, like the split-K launch: the XCDs' full-round counts can differ by a whole round, which only the ticket loop absorbs)
       if (main_tiles > 0) {
         if (use_v8) hipLaunchKernelGGL(gemm_bf16_v8_kernel<EPI>, dim3(main_tiles < n_cu ? main_tiles : n_cu), dim3(256), 2 * STAGE4 + 2048, s, g2);
         else hipLaunchKernelGGL(gemm_bf16_v6_kernel<EPI>, dim3(main_tiles < n_cu ? main_tiles : n_cu), dim3(512), smem, s, g2);
       }
-      hipLaunchKernelGGL(gemm_tail128_kernel<EPI>, dim3(8 * tb * 4), dim3(256), smem1, s, g2);
+      if (4 * tb <= per) hipLaunchKernelGGL((gemm_tail128_kernel<EPI, true>), dim3(8 * tb * 4), dim3(256), 8 * TILE_BYTES, s, g2);
+      else hipLaunchKernelGGL((gemm_tail128_kernel<EPI, false>), dim3(8 * tb * 4), dim3(256), 4 * TILE_BYTES, s, g2);
       return hipGetLastError();
     }
   }
