@@ -24,11 +24,15 @@ launch on the launch stream: that pass gives the `eager` figures printed beside 
 and the rocprofv3 kernel trace of this command, profiles/, covers both passes).  `cpu_baseline` = the oracle (a CPU port)
 timed on a bounded sample: one transformer block per stage shape.
 
-N > 1: one process per GPU.  `value` is the rate ONE video can be generated at: lane l+1 cannot start its chunk before
-lane l has finished its anchor stage, so at most chunk_time / anchor_time (~3.5 at 14B/720p) chunk lanes are ever busy;
-from 4 ranks on the ranks are therefore paired (cond | uncond branch of the classifier-free guidance on two GPUs, the
-reference's device_cond / device_uncond seam) and W/2 lanes run twice as fast (`--no-cfg-split` / `--cfg-split` override).
-The N-independent-chunks aggregate is printed as `value_independent_chunks`.
+N > 1: one process per GPU, and the default line is a MEASUREMENT of the path the reference's multi-GPU scripts run: ONE video of
+C = 2 x lanes chunks through the real pipeline and the real dependency chain (chunk c on lane c % lanes, anchors handed lane ->
+lane + 1 over RCCL after the anchor stage; from 4 ranks on the ranks are paired cond | uncond, the reference's device_cond /
+device_uncond seam, `--no-cfg-split` / `--cfg-split` override).  `value` = 21 C / wall (first noise -> last latent).  To fit a
+driver run, the UniPC steps per stage are chosen from a wall-clock budget (`--wavefront-budget-s`, `--sampling-steps 50` = the
+reference's); every stage's time is proportional to its forwards (2 K + 2), so the shortened run's wall is scaled by 102 / (2 K + 2)
+and both numbers are printed (`value` scaled, `value_shortened_run` raw, `value_modelled` = the occupancy model).  `--rotation`
+prints the K-rotating-steps line of N = 1 on every rank instead (`value` = lanes the wavefront can keep busy x 21 / chunk time:
+a model, labelled so).
 """
 from __future__ import annotations
 
@@ -84,8 +88,15 @@ def parse():
                     help="C > 0: instead of K rotating steps, run ONE video of C chunks through the real pipeline and the real dependency chain "
                          "(chunk c on lane c %% lanes, RCCL anchor hand-off after the anchor stage, VAE consumer transform) and report the MEASURED "
                          "wall clock first noise -> last latent: value = 21 C / wall (SURVEY 8d), per-rank busy fraction, stagger, hand-off latency")
-    ap.add_argument("--sampling-steps", type=int, default=50, help="UniPC steps per stage of --wavefront-chunks (50 = the reference's; fewer = a "
-                         "shorter functional run whose value is NOT the metric and is labelled so)")
+    ap.add_argument("--sampling-steps", type=int, default=None, help="UniPC steps per stage of the measured wavefront (50 = the reference's and the "
+                         "default on one rank; N > 1 default: chosen from --wavefront-budget-s; fewer than 50 = a shortened run whose wall clock is "
+                         "scaled by 102 / (2 K + 2) and labelled so)")
+    ap.add_argument("--wavefront-budget-s", type=float, default=420.0, help="N > 1 default line: wall-clock budget of the measured wavefront's timed region")
+    ap.add_argument("--rotation", action="store_true", help="N > 1: the K-rotating-steps line (occupancy MODEL for `value`) instead of the measured wavefront")
+    ap.add_argument("--attn-stats", action="store_true", help="count the self-attention blocks the FAST softmax pass could not hold (one atomic per "
+                         "256-row block inside the timed region; always on with --heavy-tail)")
+    ap.add_argument("--probe-seconds", type=float, default=1.5, help="same-run calibration: seconds of back-to-back MFMAs per instruction shape right "
+                         "before the warm-up (0 = skip)")
     ap.add_argument("--heavy-tail-gain", type=float, default=8.0, help="QK-norm gain multiplier of --heavy-tail (8 = the test's; logit std ~ gain^2 nats)")
     ap.add_argument("--heavy-tail", action="store_true",
                     help="NOT the headline: the statistics real checkpoints have and unit-variance synthetic weights do not (QK-norm gains x8, "
@@ -193,7 +204,6 @@ def run_wavefront(args, dist, rank, world, dev, gloo):
     from mmpl_amd.synthetic import WAN_CONFIGS, dit_state_dict, vae_state_dict
     from mmpl_amd.wan_wrapper import SyntheticTextEncoder, WanFPSWrapper, WanVAEWrapper
     torch.set_grad_enabled(False)
-    C_ = args.wavefront_chunks
     cfg = WAN_CONFIGS[args.model]
     lat_h, lat_w = (16, 24) if args.res == "tiny" else RESOLUTIONS[args.res]
     geo = Geometry(lat_h, lat_w)
@@ -203,12 +213,13 @@ def run_wavefront(args, dist, rank, world, dev, gloo):
         pair, heads, lay = CfgPair.build(world, dev, True)
     n_lanes = world // 2 if pair is not None else world
     lane = lay["lane_of"][rank] if lay else rank
+    C_ = args.wavefront_chunks if args.wavefront_chunks > 0 else 2 * n_lanes
     gen = WanFPSWrapper("Wan2.1-T2V-14B", timestep_shift=5.0, is_causal=True, model_config=cfg, geometry=geo, device=str(dev))
     gen.load_state_dict(dit_state_dict(cfg, seed=1234, device=dev))
     enc = SyntheticTextEncoder(cfg.get("text_dim", 4096), str(dev))
     vae = WanVAEWrapper(geometry=geo, device=str(dev), state_dict=vae_state_dict(seed=7))
     pargs = types.SimpleNamespace(model_kwargs={}, num_train_timestep=1000, timestep_shift=5.0, guidance_scale=5.0, negative_prompt="",
-                                  independent_first_frame=False, sampling_steps=args.sampling_steps)
+                                  independent_first_frame=False, sampling_steps=args.sampling_steps or 50)
     pipe = CausalFPSInferencePipeline(pargs, str(dev), generator=gen, text_encoder=enc, vae=vae, save=None, mode="t2v", geometry=geo)
     pipe.cfg_pair = pair
     ho = None
@@ -222,6 +233,20 @@ def run_wavefront(args, dist, rank, world, dev, gloo):
     pipe.sampling_steps = 1
     _, lat = pipe.inference(noises[0].to(dev), ["warm-up"], return_latents=True, decode=False)
     handoff_to_initial_latent(vae, torch.cat([lat[:, :1], lat[:, [2, 3, 10, 11, 12, 19, 20]]], dim=1))
+    torch.cuda.synchronize()
+    if args.sampling_steps is None:
+        # UniPC steps per stage from the wall-clock budget: a second 1-step chunk (4 forwards per stage, everything warm) is timed,
+        # a K-step chunk costs (2 K + 2) / 4 of it, and the wavefront takes C / lanes chunk times + (lanes - 1) staggers of ~0.3 chunk
+        tw = time.time()
+        pipe.inference(noises[0].to(dev), ["warm-up"], return_latents=True, decode=False)
+        torch.cuda.synchronize()
+        one = torch.tensor([time.time() - tw], dtype=torch.float64)
+        if dist is not None and world > 1:
+            one = one.to("cpu" if gloo else dev)
+            dist.all_reduce(one, op=dist.ReduceOp.MAX)
+        chunks_of_wall = (C_ + n_lanes - 1) // n_lanes + 0.3 * (n_lanes - 1)
+        k = int((args.wavefront_budget_s / (chunks_of_wall * one.item() / 4.0) - 2.0) / 2.0)
+        args.sampling_steps = max(2, min(50, k)) if world > 1 else 50
     pipe.sampling_steps = args.sampling_steps
     torch.cuda.synchronize()
     marks = {}
@@ -292,22 +317,34 @@ def run_wavefront(args, dist, rank, world, dev, gloo):
         busy[chunks[c]["rank"]] = busy.get(chunks[c]["rank"], 0.0) + chunks[c]["t_end"] - chunks[c]["t_start"]
     lat_ho = {c: st["t_recv_done"] - max(st.get("t_sink", 0.0), st.get("t_ready", 0.0)) for c, st in ho_stats.items() if "t_recv_done" in st}
     wait_ho = {c: max(0.0, st["t_sink"] - st["t_ready"]) for c, st in ho_stats.items() if "t_sink" in st and "t_ready" in st}
-    value = 21.0 * C_ / wall
+    full = args.sampling_steps == 50
+    # every stage of every chunk runs 2 K + 2 forwards (K denoise steps x (cond, uncond) + the refresh pair), the hand-off and the
+    # consumer's VAE transform do not shrink with K: wall x 102 / (2 K + 2) is what the same wavefront takes at the reference's 50 steps
+    # up to those fixed costs (which the shortened run over-weights: the scaled value is a slight UNDER-estimate)
+    to_50 = 102.0 / (2.0 * args.sampling_steps + 2.0)
+    value_raw = 21.0 * C_ / wall
+    value = value_raw / to_50
     # the occupancy model of the default N > 1 line, fed by THIS run's chunk / anchor times (kept for comparison)
     later = dur[1:] if len(dur) > 1 else dur
     later_anchor = anchor[1:] if len(anchor) > 1 else anchor
     d_mean, a_mean = sum(later) / len(later), sum(later_anchor) / len(later_anchor)
-    modelled = min(float(n_lanes), d_mean / a_mean) * 21.0 / d_mean
+    modelled = min(float(n_lanes), d_mean / a_mean) * 21.0 / (d_mean * to_50)
     fwd_per_chunk = [(args.sampling_steps * 2 + 2) for _ in range(4)]
     flops = sum(f * n for f, n in zip(stage_flops, fwd_per_chunk)) * C_          # (chunks >= 2 skip s0's denoising: upper bound)
-    full = args.sampling_steps == 50
+    n_fwd_steps = sum(1 for c in order for _ in range(4 if c == 0 else 3)) * (args.sampling_steps + 1)
     res = {"metric": "video_latent_frames_per_sec", "value": value, "unit": "latent-frames/s",
            "n_gpus": dist.get_world_size() if dist is not None else 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "ms_per_step": sum(dur) / n_fwd_steps * 1e3, "ms_per_step_note": "busy time of all chunks / their denoise-step equivalents (K + 1 per stage run); "
+                                                                          "--steps / --warmup do not apply to the measured wavefront",
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            **({"functional_only": "gloo backend: ranks share GPUs, exchanges staged through the host -- exercises the N > 1 code paths, "
                                   "not a scaling measurement"} if gloo else {}),
-           **({} if full else {"not_the_metric": f"{args.sampling_steps} sampling steps per stage instead of the reference's 50: a functional / "
-                                                 "timing-structure run; `value` is the rate of THIS shortened video"}),
+           **({} if full else {"value_shortened_run": value_raw,
+                               "value_scaling": f"the run used {args.sampling_steps} UniPC steps per stage instead of the reference's 50 (wall-clock budget "
+                                                f"{args.wavefront_budget_s:.0f} s); `value` = 21 C / (wall x {to_50:.3f}), wall x 102 / (2 K + 2): every stage's "
+                                                "time is proportional to its 2 K + 2 forwards, the hand-off / VAE consumer transform is not (so `value` is a "
+                                                "slight under-estimate); `value_shortened_run` = 21 C / wall of the run as it was; --sampling-steps 50 measures "
+                                                "the full length"}),
            "config": {"workload": f"Wan2.1-T2V-{args.model} {args.res}: ONE video of {C_} chunks (21 latent frames each) through the real pipeline, "
                                   f"{args.sampling_steps} UniPC steps x CFG per stage, anchors handed lane -> lane + 1",
                       "frame_seqlen": S, "latent_hw": [lat_h, lat_w], "sampling_steps": args.sampling_steps, "guidance_scale": 5.0,
@@ -326,6 +363,11 @@ def run_wavefront(args, dist, rank, world, dev, gloo):
            "handoff_latency_note": "recv complete - max(anchors available on the producer, consumer ready): RCCL p2p + header (+ host staging under gloo)",
            "producer_waited_for_consumer_s": {str(c): v for c, v in sorted(wait_ho.items())},
            "achieved_pflops_all_gpus_upper_bound": flops / wall / 1e15}
+    if not args.no_cpu_baseline:
+        try:
+            res["cpu_baseline"] = cpu_baseline(cfg, lat_h, lat_w, T2V_STAGE_SHAPES, args.cpu_budget_s)
+        except Exception as e:  # the baseline is a reported extra; never lose the GPU measurement over it
+            res["cpu_baseline"] = {"value": None, "unit": "latent-frames/s", "cores": torch.get_num_threads(), "kind": "port", "sample": f"failed: {e!r}"}
     print(json.dumps(res), flush=True)
 
 
@@ -358,7 +400,7 @@ def main():
     gloo = dist is not None and args.dist_backend == "gloo"
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    if args.wavefront_chunks > 0:
+    if args.wavefront_chunks > 0 or (world > 1 and not args.rotation):
         run_wavefront(args, dist, rank, world, dev, gloo)
         if dist is not None:
             dist.barrier()
@@ -402,7 +444,8 @@ def main():
             sd["patch_embedding.bias"] = b.to(torch.bfloat16)
         eng.load_state_dict(sd)
         del sd
-    attn_stats = eng.enable_attn_stats()      # {query blocks, blocks the FAST softmax pass could not hold}: one atomic per block
+    # {query blocks, blocks the FAST softmax pass could not hold}: one atomic per block, captured into the step graphs -- diagnostic runs only
+    attn_stats = eng.enable_attn_stats() if (args.attn_stats or args.heavy_tail) else None
     S = eng.S
     plan = StagePlan(args.mode)
     stage_shapes = T2V_STAGE_SHAPES if args.mode == "t2v" else I2V_STAGE_SHAPES
@@ -415,8 +458,10 @@ def main():
         vc.normal_()
         ctx = torch.randn(512, cfg["text_dim"], device=dev).to(torch.bfloat16)
         ctx[64:] = 0
-        ck, cv = eng.precompute_context(ctx)
-        caches.append((kc, vc, ck, cv))
+        ckv = eng.precompute_context(ctx)
+        # (.., cross_rows): the padded tail of the text K / V is one repeated row from row `rows` on -- explicit data, the same
+        # path CrossAttnCache takes in the pipeline
+        caches.append((kc, vc, ckv[0], ckv[1], ckv.rows))
     # per-stage state: latents, visible slots, scheduler
     vis_frames = [[0, 1], [0, 1, 2, 3, 10, 11, 12, 19, 20], list(range(13)) + ([] if args.mode == "t2v" else [19, 20]),
                   list(range(13)) + [19, 20]]
@@ -465,15 +510,15 @@ def main():
         st["t"].fill_(float(sched.timesteps[sched.step_index]))
         if pair is None:
             for which, out in ((0, st["fc"]), (1, st["fu"])):
-                kc, vc, ck, cv = caches[which]
-                eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out)
+                kc, vc, ck, cv, crows = caches[which]
+                eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out, cross_rows=crows)
         else:
-            kc, vc, ck, cv = caches[0]
+            kc, vc, ck, cv, crows = caches[0]
             if st.get("fwd_graph") is not None and not eager:
                 xin(st)                                # (refreshes the 36-channel buffer of the i2v model type)
                 st["fwd_graph"].replay()               # this rank's branch: one hipGraph per forward
             else:
-                eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=st["mine"])
+                eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=st["mine"], cross_rows=crows)
             pair.exchange(st["mine"], st["flow"])      # host-issued 2-rank all-gather: the step cannot be ONE graph here
         sched.step_cfg(st["fc"], st["fu"], 5.0, st["lat"])
         if i % 4 == 1:
@@ -522,9 +567,9 @@ def main():
     if use_graph:
         for st in stage_state:                              # eager warm-up of every launch shape, then capture
             for which, out in ((0, st["fc"]), (1, st["fu"])):
-                kc, vc, ck, cv = caches[which]
+                kc, vc, ck, cv, crows = caches[which]
                 st["t"].fill_(999.0)
-                eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out)
+                eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out, cross_rows=crows)
             sched = st["sched"]
             sched.build_step_table(5.0, dev)
             sched._ensure_state(st["lat"])
@@ -533,16 +578,26 @@ def main():
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 for which, out in ((0, st["fc"]), (1, st["fu"])):
-                    kc, vc, ck, cv = caches[which]
-                    eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out)
+                    kc, vc, ck, cv, crows = caches[which]
+                    eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out, cross_rows=crows)
                 sched.step_cfg_table(st["fc"], st["fu"], st["lat"], st["t"])
             st["graph"], st["replays"] = g, 0
     if pair is not None and not args.eager:
         # CFG pair: each rank's forward is a hipGraph (the per-step exchange of the two flow predictions is issued by the host)
         for st in stage_state:
-            kc, vc, ck, cv = caches[0]
+            kc, vc, ck, cv, crows = caches[0]
             st["t"].fill_(999.0)
-            st["fwd_graph"] = eng.capture(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, st["mine"])
+            st["fwd_graph"] = eng.capture(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, st["mine"], cross_rows=crows)
+    # same-run calibration of THIS box: what it sustains on nothing but MFMAs (random operands), per instruction shape, right before
+    # the warm-up steps (which bring clocks / power back to the workload's own steady state before the timed region)
+    probe = None
+    if args.probe_seconds > 0:
+        probe = {}
+        torch.cuda.synchronize()
+        for shape, name in ((32, "v_mfma_f32_32x32x16_bf16"), (16, "v_mfma_f32_16x16x32_bf16")):
+            tf = C.c_double(0.0)
+            _lib.check(lib.mmpl_probe_mfma_tflops(shape, args.probe_seconds, C.byref(tf)), "mmpl_probe_mfma_tflops")
+            probe[name] = tf.value
     for i in range(args.warmup):
         one_step(i)
     handoff_exchange(stage_state[1])       # untimed: the p2p communicators exist before the timed region whatever --warmup is
@@ -555,7 +610,8 @@ def main():
     # the K timed steps keep rotating through the four stage shapes; every step is also bracketed by a HIP event pair so
     # that the chunk time can be assembled per stage (exact for any K, not only multiples of 4)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    attn_stats.zero_()
+    if attn_stats is not None:
+        attn_stats.zero_()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -566,7 +622,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     step_s = [e0.elapsed_time(e1) * 1e-3 for e0, e1 in ev]
-    attn_blocks, attn_redone = eng.read_attn_stats()        # of the timed region (graph replays included)
+    attn_blocks, attn_redone = eng.read_attn_stats() if attn_stats is not None else (None, None)   # of the timed region (graph replays included)
     # ---- eager pass (after the timed region when that one replayed graphs): one rotation of the four stages with a hipEvent
     # pair around every self-attention launch (all kernel classes with --profile-all) -> `eager` figures and `roofline`
     eager_step_s = None
@@ -637,6 +693,8 @@ def main():
             "n_gpus": dist.get_world_size() if dist is not None else 1,        # the ranks RCCL actually connected
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            **({"value_is_modelled": "--rotation with N > 1: `value` = lanes the wavefront can keep busy x 21 / chunk time from this run's stage "
+                                     "times -- an occupancy model; the default N > 1 line measures the dependent wavefront instead"} if world > 1 else {}),
             **({"functional_only": "gloo backend: ranks share GPUs, exchanges staged through the host -- exercises the N > 1 code "
                                    "paths, not a scaling measurement"} if gloo else {}),
             "config": {"workload": f"Wan2.1-{args.mode.upper()}-{args.model} {args.res} chunk-AR denoise step (cond+uncond DiT forward, CFG, UniPC), "
@@ -660,8 +718,8 @@ def main():
             "vae_decode_s_per_chunk": vae_s,
             # data dependence of the self-attention kernel IN THE TIMED REGION: 256-row query blocks whose max-free FAST softmax pass
             # overflowed / underflowed and were redone by the GENERAL pass (attn_w64.hip); caches hold K / V written by real forwards
-            "attn_blocks": attn_blocks, "attn_blocks_redone": attn_redone,
-            "attn_blocks_redone_fraction": (attn_redone / attn_blocks) if attn_blocks else None,
+            **({"attn_blocks": attn_blocks, "attn_blocks_redone": attn_redone,
+                "attn_blocks_redone_fraction": (attn_redone / attn_blocks) if attn_blocks else None} if attn_stats is not None else {}),
             **({"weights": f"heavy-tailed synthetic (QK-norm gains x{args.heavy_tail_gain:g}, six massive-activation channels): NOT the headline workload"}
                if args.heavy_tail else {}),
         }
@@ -689,6 +747,12 @@ def main():
                                "measured_in": ("eager pass right after the timed graph replays (hipEvent pair per launch on the launch stream)"
                                                if graphed else "timed region (hipEvent pair per launch on the launch stream)"),
                                "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+                               **({"sustained_probe_tflops": probe,
+                                   "frac_of_sustained": ach / probe["v_mfma_f32_32x32x16_bf16"],
+                                   "sustained_probe_note": f"mmpl_probe_mfma_tflops: {args.probe_seconds:g} s per shape of back-to-back MFMAs on random bf16 operands (one wave "
+                                                           "per SIMD, accumulators in AGPRs) on this box right before the warm-up steps; the attention kernel issues the "
+                                                           "32x32x16 shape: frac_of_sustained = achieved / that shape's sustained rate (the chip is power-limited: the nominal "
+                                                           "`peak` is not reachable on non-zero operands)"} if probe else {}),
                                "traffic": traffic, "traffic_unit": "fabric bytes per op (L2 <-> memory side; Infinity-Cache hits are counted, so this is an upper bound of HBM bytes)",
                                "traffic_source": traffic_src,
                                "avg_launch_ms": a["ms"] / a["launches"], "launches": a["launches"],
@@ -701,6 +765,8 @@ def main():
             if "gemm" in prof:
                 g = prof["gemm"]
                 res["gemm_tflops"] = g["flops"] / (g["ms"] * 1e-3) / 1e12
+                if probe:
+                    res["gemm_frac_of_sustained"] = res["gemm_tflops"] / probe["v_mfma_f32_16x16x32_bf16"]
         if isinstance(vae_s, float):
             # hook-counted conv + attention FLOPs of the reference decoder (vae.py:545-569), 10.54 TFLOP for the first
             # latent frame + 31.77 TFLOP per further one at 720p (90 x 160 latents), proportional to h * w
@@ -709,7 +775,7 @@ def main():
                                    "achieved": vfl / vae_s / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": vfl / vae_s / 1e12 / MFMA_PEAK_TFLOPS, "algorithmic_flops": vfl, "seconds": vae_s,
                                    "note": "reported beside the DiT metric, not part of `value` (0.35 % of a chunk)"}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:           # rank 0 only (this branch), whatever the world size
             try:
                 res["cpu_baseline"] = cpu_baseline(cfg, lat_h, lat_w, stage_shapes, args.cpu_budget_s)
             except Exception as e:  # the baseline is a reported extra; never lose the GPU measurement over it

@@ -45,9 +45,15 @@ size_t mmpl_dit_workspace_bytes(const MmplDit* h, int n_frames);
 size_t mmpl_dit_context_workspace_bytes(const MmplDit* h);
 
 /* text_embedding + per-layer cross-attn K/V (causal_fps_model.py:780-786, model.py:175-180), once per prompt.
- * context: dev [text_len, text_dim] zero-padded; cross_k/cross_v: dev out [num_layers, text_len, dim]. */
+ * context: dev [text_len, text_dim] zero-padded; cross_k/cross_v: dev out [num_layers, text_len, dim].
+ * distinct_rows (host out, may be NULL): n such that rows n .. text_len-1 of the EMBEDDED context are bitwise identical (the
+ * reference zero-pads the T5 output and attends over the padding unmasked, utils/wan_wrapper.py:46-47, model.py:189, so after
+ * the text embedding the padded tail is one repeated row, and so are its K and V rows in every block); text_len when the tail
+ * does not repeat.  Determined on the device with one 2 KiB read-back (synchronises `stream`); inside a stream capture nothing
+ * is read back and text_len is reported.  It is a property of the K/V CONTENTS: it stays valid for any copy of cross_k/cross_v
+ * and is what mmpl_dit_forward takes as `cross_rows`. */
 int mmpl_dit_precompute_context(MmplDit* h, const void* context, void* cross_k, void* cross_v, void* workspace,
-                                size_t workspace_bytes, mmpl_stream_t stream);
+                                size_t workspace_bytes, int* distinct_rows, mmpl_stream_t stream);
 
 /* Wan-I2V model type (WanModel(model_type='i2v'), wan/modules/model.py:563-616,672-712): in_dim = 36 (x and the
  * conditioning video y concatenated on the channel axis, model.py:680-681 -- the caller concatenates) and every block's
@@ -72,10 +78,15 @@ int mmpl_dit_set_attn_stats(MmplDit* h, void* stats_dev);
  *                (the reference's [13..18] stage, causal_fps_model.py:254-264)
  *   visible_slots: host, cache slots attended (attention_vis_index after the 19,20 -> 13,14 remap)
  *   k_cache / v_cache: dev [num_layers, n_slots * S, dim], mutated in place like the reference's kv_cache
- *   cross_k / cross_v: from mmpl_dit_precompute_context */
+ *   cross_k / cross_v: from mmpl_dit_precompute_context (or any copy of them)
+ *   cross_rows : the caller's statement that rows cross_rows .. text_len-1 of every layer of cross_k (and of cross_v) are copies
+ *                of row cross_rows -- the `distinct_rows` mmpl_dit_precompute_context reported for these contents.  The text
+ *                cross-attention then attends over rows 0 .. cross_rows with the last one weighted text_len - cross_rows times:
+ *                the same softmax, (text_len - cross_rows - 1) fewer keys.  text_len (or any value outside [0, text_len - 2])
+ *                = attend over all text_len rows, which is always correct. */
 int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int n_frames, const int* frame_ids,
                      const int* write_slots, const int* visible_slots, int n_visible, void* k_cache, void* v_cache,
-                     int n_slots, const void* cross_k, const void* cross_v, void* out, void* workspace,
+                     int n_slots, const void* cross_k, const void* cross_v, int cross_rows, void* out, void* workspace,
                      size_t workspace_bytes, mmpl_stream_t stream);
 
 /* attention() seam (wan/modules/attention.py:139-185) over paged K/V.  q/o: row r, head h at base + r*ld + h*128.
@@ -127,6 +138,12 @@ size_t mmpl_gemm_scratch_bytes(void);
  * 0.  The tile / head orders use that mapping for L2 locality only; since round 4 no kernel depends on it for correctness (the
  * split-K launch exchanges its partials with system-scope accesses).  Synchronises on first use: not inside a stream capture. */
 int mmpl_device_xcd_round_robin(void);
+/* Calibration of the box a measurement runs on: the rate (TFLOP/s, dense bf16) the current device sustains on nothing but
+ * back-to-back MFMAs on random operands, one wave per SIMD, accumulators in the accumulator file; shape 32 =
+ * v_mfma_f32_32x32x16_bf16 (the attention kernels), 16 = v_mfma_f32_16x16x32_bf16 (GEMM, VAE).  Runs for about `seconds` on the
+ * null stream and synchronises; reports the second half of the run.  MI355X is power-limited under dense MFMA streams, so this --
+ * not the nominal 2.5 PFLOP/s -- is the ceiling wall clock can be priced against on THIS box (bench.py `roofline.sustained_probe_tflops`). */
+int mmpl_probe_mfma_tflops(int shape, double seconds, double* tflops);
 int mmpl_gemm_scratch(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N, int K,
                       int epi, const void* res, int ldres, const void* gate, int gate_frame_stride, int rows_per_frame,
                       void* scratch, size_t scratch_bytes, mmpl_stream_t stream);

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmmpl_hip.so")
 SYMBOLS = [
     "mmpl_dit_num_weights", "mmpl_dit_weight_name", "mmpl_dit_create", "mmpl_dit_destroy", "mmpl_dit_bind_weights",
     "mmpl_dit_workspace_bytes", "mmpl_dit_context_workspace_bytes", "mmpl_dit_precompute_context", "mmpl_dit_forward", "mmpl_dit_set_attn_stats", "mmpl_dit_set_image_kv", "mmpl_clip_visual", "mmpl_clip_visual_workspace_bytes",
-    "mmpl_attn_fwd", "mmpl_attn_fwd_ws", "mmpl_attn_fwd_variant", "mmpl_attn_workspace_bytes", "mmpl_gemm", "mmpl_gemm_tickets", "mmpl_gemm_scratch", "mmpl_gemm_scratch_bytes", "mmpl_device_xcd_round_robin", "mmpl_layernorm", "mmpl_qknorm_rope", "mmpl_cfg_unipc_step", "mmpl_cfg_unipc_step_table",
+    "mmpl_attn_fwd", "mmpl_attn_fwd_ws", "mmpl_attn_fwd_variant", "mmpl_attn_workspace_bytes", "mmpl_gemm", "mmpl_gemm_tickets", "mmpl_gemm_scratch", "mmpl_gemm_scratch_bytes", "mmpl_device_xcd_round_robin", "mmpl_probe_mfma_tflops", "mmpl_layernorm", "mmpl_qknorm_rope", "mmpl_cfg_unipc_step", "mmpl_cfg_unipc_step_table",
     "mmpl_vae_num_weights", "mmpl_vae_weight_name", "mmpl_vae_create", "mmpl_vae_destroy", "mmpl_vae_bind_weights",
     "mmpl_vae_workspace_bytes", "mmpl_vae_decode", "mmpl_vae_encode",
     "mmpl_t5_num_weights", "mmpl_t5_create", "mmpl_t5_destroy", "mmpl_t5_bind_weights", "mmpl_t5_workspace_bytes", "mmpl_t5_encode",
@@ -69,9 +69,9 @@ def load() -> C.CDLL:
     lib.mmpl_dit_workspace_bytes.restype = sz
     lib.mmpl_dit_context_workspace_bytes.argtypes = [vp]
     lib.mmpl_dit_context_workspace_bytes.restype = sz
-    lib.mmpl_dit_precompute_context.argtypes = [vp, vp, vp, vp, vp, sz, vp]
+    lib.mmpl_dit_precompute_context.argtypes = [vp, vp, vp, vp, vp, sz, C.POINTER(ci), vp]
     lib.mmpl_dit_forward.argtypes = [vp, vp, vp, ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), ci, vp, vp, ci, vp, vp,
-                                     vp, vp, sz, vp]
+                                     ci, vp, vp, sz, vp]
     lib.mmpl_attn_fwd.argtypes = [vp, ci, vp, ci, C.POINTER(vp), C.POINTER(vp), ci, ci, ci, ci, ci, ci, cf, vp]
     lib.mmpl_attn_fwd_ws.argtypes = [vp, ci, vp, ci, C.POINTER(vp), C.POINTER(vp), ci, ci, ci, ci, ci, ci, cf, vp, sz, vp]
     lib.mmpl_attn_fwd_variant.argtypes = [vp, ci, vp, ci, C.POINTER(vp), C.POINTER(vp), ci, ci, ci, ci, ci, ci, cf, vp, sz, ci, ci, vp]
@@ -83,6 +83,7 @@ def load() -> C.CDLL:
     lib.mmpl_gemm_scratch.argtypes = [vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, ci, vp, sz, vp]
     lib.mmpl_gemm_scratch_bytes.argtypes = []
     lib.mmpl_device_xcd_round_robin.argtypes = []
+    lib.mmpl_probe_mfma_tflops.argtypes = [ci, C.c_double, C.POINTER(C.c_double)]
     lib.mmpl_gemm_scratch_bytes.restype = sz
     lib.mmpl_layernorm.argtypes = [vp, ci, vp, ci, ci, ci, cf, vp, vp, ci, ci, vp, vp, vp]
     lib.mmpl_qknorm_rope.argtypes = [vp, vp, ci, vp, ci, vp, ci, vp, vp, ci, C.POINTER(ci), C.POINTER(vp), C.POINTER(vp), vp]

@@ -102,11 +102,6 @@ struct MmplDit {
   float* cos_tab = nullptr;  // [1024][64]
   float* sin_tab = nullptr;
   std::vector<const bf16_t*> w;
-  // text contexts whose zero-padded tail is ONE repeated row after the text embedding (utils/wan_wrapper.py:46-47 zeroes the
-  // padding, causal_fps_model.py:780 does not mask it): cross_k buffer -> number of distinct leading rows n; rows n .. text_len-1
-  // of that context's K (and V) are identical, so the cross-attention attends over n + 1 keys, the last one weighted
-  // text_len - n times (mmpl_dit_precompute_context fills this, mmpl_dit_forward looks its cross_k argument up)
-  std::vector<std::pair<const void*, int>> ctx_distinct;
   unsigned long long* attn_stats = nullptr;    // mmpl_dit_set_attn_stats: {blocks, blocks redone} of the self-attention launches
   const bf16_t* G(int i) const { return w[i]; }
   const bf16_t* Lw(int l, int i) const { return w[NG + l * NL + i]; }
@@ -272,7 +267,7 @@ size_t mmpl_dit_context_workspace_bytes(const MmplDit* h) {
 }
 
 int mmpl_dit_precompute_context(MmplDit* h, const void* context, void* cross_k, void* cross_v, void* workspace,
-                                size_t workspace_bytes, mmpl_stream_t stream) {
+                                size_t workspace_bytes, int* distinct_rows, mmpl_stream_t stream) {
   if (!h || h->w.empty()) return fail("mmpl_dit_precompute_context", "weights not bound");
   if (workspace_bytes < mmpl_dit_context_workspace_bytes(h)) return fail("mmpl_dit_precompute_context", "workspace too small");
   const MmplDitConfig& c = h->cfg;
@@ -287,15 +282,16 @@ int mmpl_dit_precompute_context(MmplDit* h, const void* context, void* cross_k, 
   // How many leading rows of the embedded context are distinct from its last row?  The reference zeroes the padded rows of the
   // T5 output (utils/wan_wrapper.py:46-47) and attends over all text_len of them unmasked (causal_fps_model.py:780, model.py:189):
   // after the text embedding the T - n padded rows are ONE repeated row, so are their K and V rows in every block, and
-  // softmax over {k_0..k_{n-1}, (T - n) x k_pad} == softmax over {k_0..k_{n-1}, k_pad + ln(T - n)}: the forward attends over n + 1
-  // keys (the bench's 64-token prompt: 2 KV tiles instead of 8).  Checked on the device per prompt (bitwise row compare of what
-  // the K / V projections read); one 2 KiB read-back -- not inside a stream capture, where nothing is collapsed.
-  {
-    for (size_t i = 0; i < h->ctx_distinct.size(); ++i)
-      if (h->ctx_distinct[i].first == cross_k) { h->ctx_distinct.erase(h->ctx_distinct.begin() + i); break; }
+  // softmax over {k_0..k_{n-1}, (T - n) x k_pad} == softmax over {k_0..k_{n-1}, k_pad + ln(T - n)}: a forward told so (cross_rows)
+  // attends over n + 1 keys (the bench's 64-token prompt: 2 KV tiles instead of 8).  Checked on the device per prompt (bitwise
+  // row compare of what the K / V projections read); one 2 KiB read-back -- not inside a stream capture, where T is reported.
+  // The count is handed to the CALLER: it describes the contents, so it travels with every copy of them (round 4 kept it in
+  // the handle keyed by the cross_k pointer, which a re-used address could inherit).
+  if (distinct_rows) {
+    *distinct_rows = T;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cs);
-    if (cs == hipStreamCaptureStatusNone && !mmpl_config().cross_no_collapse && T >= 2) {
+    if (cs == hipStreamCaptureStatusNone && T >= 2) {
       int* flags = (int*)k.take(((size_t)T * sizeof(int) + 1) / sizeof(bf16_t));
       std::vector<int> hf(T);
       HIP_TRY(mmpl_launch_rows_equal_last(ctx, d, T, d, flags, s), "rows_equal_last");
@@ -303,10 +299,7 @@ int mmpl_dit_precompute_context(MmplDit* h, const void* context, void* cross_k, 
       HIP_TRY(hipStreamSynchronize(s), "context flags");
       int n = T - 1;
       while (n > 0 && hf[n - 1]) --n;                      // rows n .. T-1 are identical
-      if (T - n >= 2) {
-        if (h->ctx_distinct.size() >= 16) h->ctx_distinct.erase(h->ctx_distinct.begin());
-        h->ctx_distinct.push_back({cross_k, n});
-      }
+      if (T - n >= 2) *distinct_rows = n;
     }
   }
   for (int l = 0; l < c.num_layers; ++l) {
@@ -338,7 +331,7 @@ int mmpl_dit_set_attn_stats(MmplDit* h, void* stats_dev) {
 
 int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, const int* frame_ids,
                      const int* write_slots, const int* visible_slots, int n_visible, void* k_cache, void* v_cache,
-                     int n_slots, const void* cross_k, const void* cross_v, void* out, void* workspace,
+                     int n_slots, const void* cross_k, const void* cross_v, int cross_rows, void* out, void* workspace,
                      size_t workspace_bytes, mmpl_stream_t stream) {
   if (!h || h->w.empty()) return fail("mmpl_dit_forward", "weights not bound");
   const MmplDitConfig& c = h->cfg;
@@ -380,9 +373,8 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
   const bool cross_w64_env = mmpl_config().cross_w64;
   const bool cross_w64 = cross_w64_env && prescale_q;       // text / image cross-attention on the 64-rows-per-wave kernel too
   const size_t layer_stride = (size_t)n_slots * S * d;
-  int ctx_n = -1;                                           // distinct leading rows of this text context, -1 = not known to collapse
-  for (const auto& e : h->ctx_distinct)
-    if (e.first == cross_k) ctx_n = e.second;
+  // rows cross_rows .. T-1 of the text K / V are one repeated row (the caller's statement, see the header); -1 = attend over all T
+  const int ctx_n = (cross_rows >= 0 && cross_rows <= T - 2) ? cross_rows : -1;
   for (int l = 0; l < c.num_layers; ++l) {
     const bf16_t* em = w.emod + (size_t)l * nF * 6 * d;  // [nF][6][d]
     bf16_t* kc = (bf16_t*)k_cache + (size_t)l * layer_stride;

@@ -52,7 +52,14 @@ namespace {
 constexpr int QB = 256, KVB = 64, TILE = KVB * 256, RING = 4;         // K ring [0, 64 KiB), V ring [64 KiB, 128 KiB)
 constexpr int W64_SMEM = 2 * RING * TILE + 64;     // + the block's redo flag
 constexpr float BOUND_GEN = 1073741824.f;                              // 2^30: a GENERAL tile's partial row sums
-constexpr float FAST_L_MIN = 7.888609e-31f, FAST_L_MAX = 1.2676506e30f;       // 2^-100, 2^100: a FAST pass's final row sums
+#ifndef W64_LMIN_EXP
+#define W64_LMIN_EXP 100
+#endif
+#ifndef W64_LMAX_EXP
+#define W64_LMAX_EXP 100
+#endif
+constexpr float pow2f(int e) { return e == 0 ? 1.f : (e > 0 ? 2.f * pow2f(e - 1) : 0.5f * pow2f(e + 1)); }
+constexpr float FAST_L_MIN = pow2f(-W64_LMIN_EXP), FAST_L_MAX = pow2f(W64_LMAX_EXP);   // 2^-100, 2^100: a FAST pass's final row sums
 #ifndef W64_REF_OFFSET
 #define W64_REF_OFFSET 64
 #endif
@@ -69,34 +76,18 @@ constexpr int AO = 0, AQ = 128, AV = 192;      // accumulator-file map
 
 // Timing ablations for tools/w64_sweep.sh (results are garbage): -DW64_ABL=<bits>  1 no LDS-DMA in the loop, 2 no softmax,
 // 4 no fragment reads, 8 no barrier / waits, 16 leave per-wave loop cycle counts in o (tools/attn_dev.py cycles), 32 / 64 / 128
-// no exp / row-sum adds / bf16 packs.  0 in every shipped build.
+// no exp / row-sum adds / bf16 packs, 256 every V fragment by ONE ds_read_b128 in K's conflict-free lane pattern instead of two
+// ds_read_b64_tr_b16 (what a V tile stored pre-transposed would cost: same LDS bytes, half the V read instructions).  0 in every
+// shipped build.
 #ifndef W64_ABL
 #define W64_ABL 0
 #endif
-// Dev timing mock (tools/gen_attn_w64_mock16.py, results are garbage): -DW64_MOCK16=1 issues every MFMA of the loop as two
-// v_mfma_f32_16x16x32_bf16 on the same operand registers (accumulator chains as long as a native 16-wide kernel's) with the fillers
-// scheduled into 128 gaps of 16 cycles.  0 in every shipped build.
-#ifndef W64_MOCK16
-#define W64_MOCK16 0
-#endif
-#if W64_MOCK16
-#define SREG(X, h, e) S4[X][h][(e) >> 2][(e) & 3]
-#define MREG(h, r) M4[h][(r) >> 2][(r) & 3]
-#else
-#define SREG(X, h, e) S[X][h][e]
-#define MREG(h, r) M[h][r]
-#endif
-
 // All state of a wave.  Passed by reference through always-inlined members, so every field ends up in a register (VGPR or,
 // when provably wave-uniform, SGPR); arrays are only ever indexed with compile-time constants.
 struct Ctx {
   // ---- vector state
-#if W64_MOCK16
-  f32x4 S4[2][2][4], M4[2][4];
-#else
   f32x16 S[2][2];        // [query block][kv half]
   f32x16 M[2];           // [kv half] C operand of a score tile's first MFMA: 0, or -inf on the rows past a page's end
-#endif
   u32x4 P[2][4];         // [query block][16-row kv step]: 8 bf16 = B operand of O^T += V^T.P^T
   bf16x8 kf[16];         // K fragments of one tile: i = 2*chunk + half
   float l[2], mref[2];   // running row sum (this lane's 32 kv columns of every tile) and reference (log2 units)
@@ -122,7 +113,6 @@ struct Ctx {
   unsigned long long ticks;                    // W64_ABL & 16: shader cycles of the pass's steady loop
 
   // ---------------------------------------------------------------- MFMAs
-#if !W64_MOCK16
   template <int X, int G> MMPL_DEV void mfma_qk() {      // S_X[h] (+)= K frag G . Q_X[chunk]
     constexpr int c = G >> 1, h = G & 1, qa = AQ + 32 * X + 4 * c;
     if constexpr (c == 0)
@@ -130,31 +120,16 @@ struct Ctx {
     else
       asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(S[X][h]) : "v"(kf[G]), "i"(qa), "i"(qa + 3));
   }
-#else
-  // mock: the score FLOPs of MFMA (X, G) as two 16x16x32; S register group 2 (c & 1) + HALF of S_X[h] collects the 4 chunks of its parity
-  template <int X, int G, int HALF> MMPL_DEV void mfma_qk_h() {
-    constexpr int c = G >> 1, h = G & 1, qa = AQ + 32 * X + 4 * c, grp = 2 * (c & 1) + HALF;
-    if constexpr (c < 2)
-      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, a[%c2:%c3], %4" : "=&v"(S4[X][h][grp]) : "v"(kf[G]), "i"(qa), "i"(qa + 3), "v"(M4[h][grp]));
-    else
-      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(S4[X][h][grp]) : "v"(kf[G]), "i"(qa), "i"(qa + 3));
-  }
-#endif
   template <int X, int G> MMPL_DEV void mfma_pv() {      // O_X[nb] += V frag G . P_X[ks]
     constexpr int ks = G >> 2, nb = G & 3, oa = AO + 64 * X + 16 * nb, va = AV + 4 * G;
     asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], a[%c2:%c3], %4, a[%c0:%c1]" ::"i"(oa), "i"(oa + 15), "i"(va), "i"(va + 3),
                  "v"(P[X][ks]));
   }
-  // dev timing mocks (garbage results): the PV FLOPs as two 16x16x32 MFMAs per 32x32x16 one (-DW64_ABL=256 + W64_PVSPLIT=1 schedule, or
-  // the whole loop with -DW64_MOCK16=1); O register group 2 (ks & 1) + HALF of O_X[nb]: two MFMAs per group and KV tile, as in a native kernel
-  template <int X, int G, int HALF> MMPL_DEV void mfma_pv_h() {
-    constexpr int ks = G >> 2, nb = G & 3, oa = AO + 64 * X + 16 * nb + 4 * (2 * (ks & 1) + HALF), va = AV + 4 * G;
-    asm volatile("v_mfma_f32_16x16x32_bf16 a[%c0:%c1], a[%c2:%c3], %4, a[%c0:%c1]" ::"i"(oa), "i"(oa + 3), "i"(va), "i"(va + 3), "v"(P[X][ks]));
-  }
   // ---------------------------------------------------------------- LDS fragment reads
   MMPL_DEV void addr_k() { if constexpr (W64_ABL & 4) return; asm volatile("v_add_u32 %0, %1, %2" : "=v"(kaddr) : "s"(rk), "v"(kbase)); }
   MMPL_DEV void addr_v() {
     if constexpr (W64_ABL & 4) return;
+    if constexpr (W64_ABL & 256) { asm volatile("v_add_u32 %0, %1, %2" : "=v"(vaddr[0]) : "s"(rv), "v"(kbase + RING * TILE)); return; }
     asm volatile("v_add_u32 %0, %4, %5\n\tv_xor_b32 %1, 64, %0\n\tv_xor_b32 %2, 0x80, %0\n\tv_xor_b32 %3, 0xc0, %0"
                  : "=&v"(vaddr[0]), "=&v"(vaddr[1]), "=&v"(vaddr[2]), "=&v"(vaddr[3]) : "s"(rv), "v"(vbase));
   }
@@ -168,6 +143,14 @@ struct Ctx {
   }
   template <int G> MMPL_DEV void lds_v() {               // fragment G = (ks, nb) -> a[192 + 4G ..]
     if constexpr (W64_ABL & 4) return;
+    if constexpr (W64_ABL & 256) {                          // mock: lds_k's address walk on the V ring, straight into the accumulator file
+      constexpr int va_ = AV + 4 * G, off_ = (G & 1) * 32 * 256, cs = G >> 1;
+      if constexpr ((G & 1) == 0 && G > 0)
+        asm volatile("v_xor_b32 %0, %1, %0\n\tds_read_b128 a[%c2:%c3], %0 offset:%c4" : "+v"(vaddr[0]) : "i"((32 * cs) ^ (32 * (cs - 1))), "i"(va_), "i"(va_ + 3), "i"(off_));
+      else
+        asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" ::"v"(vaddr[0]), "i"(va_), "i"(va_ + 3), "i"(off_));
+      return;
+    }
     constexpr int va = AV + 4 * G, off = (G >> 2) * 16 * 256;
     asm volatile("ds_read_b64_tr_b16 a[%c1:%c2], %0 offset:%c3\n\tds_read_b64_tr_b16 a[%c4:%c5], %0 offset:%c6" ::"v"(vaddr[G & 3]),
                  "i"(va), "i"(va + 1), "i"(off), "i"(va + 2), "i"(va + 3), "i"(off + 8 * 256));
@@ -251,7 +234,7 @@ struct Ctx {
     sfor<32>([self, hi4, ninf, zero, valid](auto ii) {
       constexpr int i = decltype(ii)::value, h = i >> 4, r = i & 15;
       const int thr = valid - (32 * h + 8 * (r >> 2) + (r & 3));          // masked iff 4 hi >= thr
-      asm volatile("v_cmp_le_i32 vcc, %2, %1\n\tv_cndmask_b32 %0, %4, %3, vcc" : "=v"(self->MREG(h, r)) : "v"(hi4), "s"(thr), "v"(ninf), "v"(zero) : "vcc");
+      asm volatile("v_cmp_le_i32 vcc, %2, %1\n\tv_cndmask_b32 %0, %4, %3, vcc" : "=v"(self->M[h][r]) : "v"(hi4), "s"(thr), "v"(ninf), "v"(zero) : "vcc");
     });
     masked = 1;
   }
@@ -259,7 +242,7 @@ struct Ctx {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) MREG(h, r) = mbase;
+      for (int r = 0; r < 16; ++r) M[h][r] = mbase;
     masked = 0;
   }
   MMPL_DEV int plan(int j) {
@@ -303,9 +286,9 @@ struct Ctx {
     if constexpr (W64_ABL & (2 | 32)) return;
     constexpr int h = Q >> 3, e = (Q & 7) * 2 + EL;
     if constexpr (MODE == 0)
-      asm volatile("v_exp_f32 %0, %1" : "=v"(t[X][Q & 1][EL]) : "v"(SREG(X, h, e)));
+      asm volatile("v_exp_f32 %0, %1" : "=v"(t[X][Q & 1][EL]) : "v"(S[X][h][e]));
     else
-      asm volatile("v_sub_f32 %0, %1, %2\n\tv_exp_f32 %0, %0" : "=&v"(t[X][Q & 1][EL]) : "v"(SREG(X, h, e)), "v"(mref[X]));
+      asm volatile("v_sub_f32 %0, %1, %2\n\tv_exp_f32 %0, %0" : "=&v"(t[X][Q & 1][EL]) : "v"(S[X][h][e]), "v"(mref[X]));
   }
   template <int MODE, int X, int Q> MMPL_DEV void sm_e0() { sm_e<MODE, X, Q, 0>(); }
   template <int MODE, int X, int Q> MMPL_DEV void sm_e1() { sm_e<MODE, X, Q, 1>(); }
@@ -326,11 +309,11 @@ struct Ctx {
   }
   // GENERAL pass, slow path of one tile of stream X (see the header): returns the tile's partial row sum.
   template <int X> MMPL_DEV float slow(float lt) {
-    float mx = SREG(X, 0, 0);
+    float mx = S[X][0][0];
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, SREG(X, 0, r));
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[X][0][r]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, SREG(X, 1, r));
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[X][1][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     if (first[X]) {
       first[X] = 0;
@@ -352,8 +335,8 @@ struct Ctx {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int h = q >> 3, e = (q & 7) * 2;
-      const float a0 = __builtin_amdgcn_exp2f(SREG(X, h, e) - mref[X]);
-      const float a1 = __builtin_amdgcn_exp2f(SREG(X, h, e + 1) - mref[X]);
+      const float a0 = __builtin_amdgcn_exp2f(S[X][h][e] - mref[X]);
+      const float a1 = __builtin_amdgcn_exp2f(S[X][h][e + 1] - mref[X]);
       lt += a0 + a1;
       P[X][q >> 2][q & 3] = pack2bf(a0, a1);
     }
@@ -363,7 +346,7 @@ struct Ctx {
   MMPL_DEV float score_max() {                           // largest of this lane's 64 scores (both query blocks, both kv halves)
     float mx = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(fmaxf(mx, fmaxf(SREG(0, 0, r), SREG(0, 1, r))), fmaxf(SREG(1, 0, r), SREG(1, 1, r)));
+    for (int r = 0; r < 16; ++r) mx = fmaxf(fmaxf(mx, fmaxf(S[0][0][r], S[0][1][r])), fmaxf(S[1][0][r], S[1][1][r]));
     return mx;
   }
   template <int MODE, int X> MMPL_DEV void finish() {
@@ -374,11 +357,7 @@ struct Ctx {
   }
 };
 
-#if W64_MOCK16
-#include "attn_w64_sched16.inc"
-#else
 #include "attn_w64_sched.inc"
-#endif
 
 // One pass over the block's KV tiles in softmax mode MODE (0 FAST, 1 GENERAL): O in a[0:127], row sums in la / lb (FAST) or l
 // (GENERAL), references in mref.
@@ -415,7 +394,6 @@ template <int MODE> MMPL_DEV void w64_pass(Ctx& k) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   k.plan(0);
-#if !W64_MOCK16
   if constexpr (MODE == 0 && W64_ABL == 0) {
     // FAST pass reference (header): the scores of KV tile 0 for both query blocks, their largest per lane (= two query rows) + offset
     // becomes m_ref; it enters every later score through the C operand of the tile's first MFMA, so the pipeline below is untouched.
@@ -449,7 +427,6 @@ template <int MODE> MMPL_DEV void w64_pass(Ctx& k) {
     k.masked = 1;                                      // make plan() rewrite the C-operand tile (mask of tile 0 included) on the new base
     k.plan(0);
   }
-#endif
   w64_phase_a<MODE, true, false, true, false>(k);
   w64_phase_b<MODE, true, false, true, false>(k);
   [[maybe_unused]] unsigned long long tick0 = 0;
@@ -561,7 +538,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const float l_tot = k.l[X] + __shfl_xor(k.l[X], 32, 64);
       bad |= !(l_tot >= FAST_L_MIN && l_tot <= FAST_L_MAX);
     }
-    if constexpr (W64_ABL != 0 || W64_MOCK16) bad = false;
+    if constexpr (W64_ABL != 0) bad = false;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // the parked cursors' last re-fetches
     if (__any(bad) && lane == 0) *redo = 1;
     __syncthreads();

@@ -86,14 +86,13 @@ const MmplRuntimeConfig& mmpl_config() {
     auto num = [](const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; };
     MmplRuntimeConfig c{};
     c.attn_v1 = flag("MMPL_ATTN_V1"); c.attn_nosplit = flag("MMPL_ATTN_NOSPLIT"); c.attn_no_merge = flag("MMPL_ATTN_NO_MERGE");
-    c.cross_w64 = flag("MMPL_CROSS_W64"); c.cross_no_collapse = flag("MMPL_CROSS_NO_COLLAPSE");
-    c.gemm_v1 = flag("MMPL_GEMM_V1"); c.gemm_v2 = flag("MMPL_GEMM_V2"); c.gemm_direct_epilogue = flag("MMPL_GEMM_DIRECT_EPILOGUE");
-    c.gemm_static_tiles = flag("MMPL_GEMM_STATIC_TILES"); c.gemm_no_sync_sweeps = flag("MMPL_GEMM_NO_SYNC_SWEEPS");
+    c.cross_w64 = flag("MMPL_CROSS_W64");
+    c.gemm_v1 = flag("MMPL_GEMM_V1"); c.gemm_v2 = flag("MMPL_GEMM_V2");
     c.gemm_no_splitk = flag("MMPL_GEMM_NO_SPLITK"); c.gemm_no_subtile = flag("MMPL_GEMM_NO_SUBTILE");
     c.gemm_group = num("MMPL_GEMM_GROUP", 0);
     c.gemm_pf = num("MMPL_GEMM_PF", 2);
     c.gemm_v8 = num("MMPL_GEMM_V8", -1);
-    c.vae_no_halo = flag("MMPL_VAE_NO_HALO"); c.vae_no_fuse_norm = flag("MMPL_VAE_NO_FUSE_NORM");
+    c.vae_no_fuse_norm = flag("MMPL_VAE_NO_FUSE_NORM");
     return c;
   }();
   return cfg;

@@ -353,9 +353,33 @@ MMPL_DEV int swz64(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
 // at 8192^3).  With the DMA ops removed the same kernel runs at 1450-1470: the LDS-DMA issue stalls (~100 cycles per
 // op) are the remaining cost.  A BK = 32 / 4-deep-ring variant in which both groups issue their own DMA ops inside
 // their R segments was slower (twice the barriers: 1040-1150).
+// dev (cache-policy experiments on the operand streams, profiles/r05*_gemm_policy*.log): -DGEMM_POLICY_A=n / -DGEMM_POLICY_W=n: modifier
+// of the LDS-DMA loads of the activation / weight operand in the large-problem kernels: 0 none (every shipped build), 1 nt, 2 sc1, 3 sc0 sc1
+#ifndef GEMM_POLICY_A
+#define GEMM_POLICY_A 0
+#endif
+#ifndef GEMM_POLICY_W
+#define GEMM_POLICY_W 0
+#endif
+#define GEMM_POL_STR_0 ""
+#define GEMM_POL_STR_1 " nt"
+#define GEMM_POL_STR_2 " sc1"
+#define GEMM_POL_STR_3 " sc0 sc1"
+#define GEMM_POL_CAT(n) GEMM_POL_STR_##n
+#define GEMM_POL_STR(n) GEMM_POL_CAT(n)
+#define GEMM_POL_A GEMM_POL_STR(GEMM_POLICY_A)
+#define GEMM_POL_W GEMM_POL_STR(GEMM_POLICY_W)
 MMPL_DEV void glds16s(const void* base, uint32_t voff, char* lds) {
   const uint32_t dst = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)lds);
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(dst) : "memory");
+}
+MMPL_DEV void glds16s_a(const void* base, uint32_t voff, char* lds) {
+  const uint32_t dst = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)lds);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" GEMM_POL_A ::"v"(voff), "s"(base), "s"(dst) : "memory");
+}
+MMPL_DEV void glds16s_w(const void* base, uint32_t voff, char* lds) {
+  const uint32_t dst = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)lds);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" GEMM_POL_W ::"v"(voff), "s"(base), "s"(dst) : "memory");
 }
 
 #ifndef GEMM6_ABL
@@ -597,7 +621,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int row = isw ? min(n0 + 8 * p + prow, g.N - 1) : min(m0 + 8 * p + prow, g.M - 1);
     if constexpr (GEMM6_ABL & 1) row = 8 * p + prow;
     const uint32_t voff = (uint32_t)(row * (isw ? g.ldw : g.lda) + lc) * 2u;
-    glds16s(isw ? w_k : a_k, voff, st + (isw ? A4_BYTES : 0) + p * 1024);
+    if (isw) glds16s_w(w_k, voff, st + A4_BYTES + p * 1024);
+    else glds16s_a(a_k, voff, st + p * 1024);
   };
 
   f32x4 acc[2][4][4];
@@ -904,8 +929,8 @@ struct G8 {
     if constexpr (GEMM8_ABL & 1) return;
     constexpr int q = Q & 7;
     const uint32_t m = dst0 + S * STAGE4 + (Q < 8 ? 0 : A4_BYTES) + 4096 * q;
-    if constexpr (Q < 8) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(a_vo[q]), "s"(a_k), "s"(m) : "memory");
-    else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(w_vo[q]), "s"(w_k), "s"(m) : "memory");
+    if constexpr (Q < 8) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" GEMM_POL_A ::"v"(a_vo[q]), "s"(a_k), "s"(m) : "memory");
+    else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" GEMM_POL_W ::"v"(w_vo[q]), "s"(w_k), "s"(m) : "memory");
   }
   // v6's L2 prefetch of the tile's SHARE of its operand slices (see gemm_bf16_v6_kernel), one k-tile ahead of the ring's DMA: two
   // LDS-DMA dwords per wave into a dump area nobody reads.  ALWAYS two ops per wave and k-tile (lanes outside the share repeat
@@ -1169,7 +1194,6 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
   const int tiles_m_ = (g.M + BM3 - 1) / BM3;
   g2.group = env_group > 0 ? env_group : ((g.M >= 16384 && g.N < 8192 && tiles_m_ % 3 == 0) ? (g.K >= 8192 ? 2 : 3) : 4);
   // the 16-byte epilogue needs 8-element alignment of everything it touches; otherwise the direct 8-byte one
-  const bool env_direct = rc.gemm_direct_epilogue;
   // (strides AND base pointers: mmpl_gemm is public ABI and callers hand in views such as a column-offset C)
   auto al = [](const void* p, uintptr_t a) { return p == nullptr || reinterpret_cast<uintptr_t>(p) % a == 0; };
   bool ptrs_ok = al(g.C, 16) && al(g.bias, 8);
@@ -1177,15 +1201,14 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
   if (g.epi == EPI_GATE_RES) ptrs_ok = ptrs_ok && al(g.gate, 16);
   if (g.epi == EPI_BIAS_VPAGES)
     for (int i = 0; i < 8; ++i) ptrs_ok = ptrs_ok && al(g.v_dst[i], 16);
-  g2.staged_epilogue = !env_direct && ptrs_ok && g.N % 8 == 0 && g.ldc % 8 == 0 &&
+  g2.staged_epilogue = ptrs_ok && g.N % 8 == 0 && g.ldc % 8 == 0 &&
                        (g.epi != EPI_GATE_RES || (g.gate_frame_stride % 8 == 0 && g.rows_per_frame >= 128)) &&
                        ((g.epi != EPI_GATE_RES && g.epi != EPI_RES) || g.ldres % 8 == 0) &&
                        (g.epi != EPI_BIAS_VPAGES || (g.v_col0 % 8 == 0 && g.v_ld % 8 == 0));
   // L2 prefetch distance (k-tiles): 2 measured best on the 14B / 720p block shapes (+1 % qkv / o / ffn0, +6 % ffn2 whose A operand is
   // 700 MB; 1 = no gain, 4 and more lose again); MMPL_GEMM_PF=0 switches it off
   g2.pf_dist = rc.gemm_pf;
-  g2.sync_sweeps = !rc.gemm_no_sync_sweeps;
-  if (rc.gemm_static_tiles) g2.tile_counter = nullptr;
+  g2.sync_sweeps = 1;
   const int per = mmpl_cus_per_xcd(), n_cu = 8 * per;
   // Split-K launch for the partial last round.  With one tile per CU a GEMM of R * 256 + t tiles takes R + 1 rounds however small t
   // is (Wan 1.3B at 480p: 43 x 6 = 258 tiles for o / ffn2 at s1, 78 at s0; 14B / 720p s0: 580).  When every XCD's leftover (its

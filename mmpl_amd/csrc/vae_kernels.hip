@@ -588,7 +588,7 @@ hipError_t launch_halo(const ConvArgs& g, hipStream_t s) {
 
 // 3x3 (x 1 | 3) filters at stride 1 out of a volume padded by one pixel, fragment-packed weights bound, a width the kernel is built for
 bool vae_conv_uses_halo(const ConvArgs& g) {
-  return !mmpl_config().vae_no_halo && g.Wfrag != nullptr && g.kh == 3 && g.kw == 3 && (g.kt == 1 || g.kt == 3) && g.st == 1 && g.sy == 1 &&
+  return g.Wfrag != nullptr && g.kh == 3 && g.kw == 3 && (g.kt == 1 || g.kt == 3) && g.st == 1 && g.sy == 1 &&
          g.sx == 1 && g.Hp == g.Ho + 2 && g.Wp == g.Wo + 2 && g.M > 0 && g.M % (g.Ho * g.Wo) == 0 && g.Cin % 32 == 0 && (g.N % 96 == 0 || g.N <= 16);
 }
 

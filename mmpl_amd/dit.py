@@ -24,6 +24,18 @@ _GLOBAL_KEYS = ["patch_embedding.weight", "patch_embedding.bias", "text_embeddin
                 "head.modulation", "head.head.weight", "head.head.bias"]
 
 
+class CrossKV(tuple):
+    """(cross_k, cross_v) of one prompt, each [num_layers, text_len, dim], plus `rows`: rows `rows .. text_len-1` of every layer are
+    copies of row `rows` (the zero-padded tail of the text context after the text embedding; `text_len` = no repeated tail).
+    Unpacks like the plain pair; `rows` is a statement about the CONTENTS, so hand it on with any copy of them
+    (`DitEngine.forward(..., cross_rows=kv.rows)`); a forward that is not given it attends over all text_len rows."""
+
+    def __new__(cls, k: torch.Tensor, v: torch.Tensor, rows: int):
+        self = super().__new__(cls, (k, v))
+        self.rows = int(rows)
+        return self
+
+
 class DitEngine:
     def __init__(self, cfg: dict, lat_h: int, lat_w: int, device="cuda:0", max_frames: int = 7):
         self.cfg = dict(cfg)
@@ -54,6 +66,8 @@ class DitEngine:
         self._ctx_ws: Optional[torch.Tensor] = None
         self._i2v_w: Optional[dict] = None                 # img_emb + per-layer k_img / v_img / norm_k_img (model_type 'i2v')
         self._img_kv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+        self._attn_stats: Optional[torch.Tensor] = None
+        self._warm = False
 
     def __del__(self):
         try:
@@ -107,17 +121,22 @@ class DitEngine:
     # ------------------------------------------------------------------ diagnostics
     def enable_attn_stats(self) -> torch.Tensor:
         """Count the self-attention kernel's query blocks and how many of them the max-free FAST softmax pass could not hold
-        (redone by the GENERAL pass): int64 [2] on the device = {blocks, blocks redone}, incremented by every forward (hipGraph
-        replays too) until `disable_attn_stats`.  One atomic per 256-row block: not measurable in the step time."""
-        if getattr(self, "_attn_stats", None) is None:
+        (redone by the GENERAL pass): int64 [2] on the device = {blocks, blocks redone}, incremented by every later forward.
+        The counter's address is a kernel argument: a hipGraph captured while stats are on keeps counting on every replay
+        whatever `disable_attn_stats` says later, and one captured while they are off never counts.  One atomic per 256-row
+        block; `bench.py` switches it on for its diagnostic modes only."""
+        if self._attn_stats is None:
             self._attn_stats = torch.zeros(2, dtype=torch.int64, device=self.device)
         _lib.check(self._lib.mmpl_dit_set_attn_stats(self._h, _lib.ptr(self._attn_stats)), "mmpl_dit_set_attn_stats")
         return self._attn_stats
 
     def disable_attn_stats(self) -> None:
+        """Later eager forwards and later captures stop counting (graphs captured before keep their setting)."""
         _lib.check(self._lib.mmpl_dit_set_attn_stats(self._h, None), "mmpl_dit_set_attn_stats")
 
     def read_attn_stats(self, reset: bool = False) -> Tuple[int, int]:
+        if self._attn_stats is None:
+            raise RuntimeError("DitEngine.read_attn_stats: enable_attn_stats() was never called on this engine")
         blocks, redone = (int(v) for v in self._attn_stats.cpu())
         if reset:
             self._attn_stats.zero_()
@@ -131,18 +150,25 @@ class DitEngine:
         return (torch.zeros(shape, dtype=torch.bfloat16, device=self.device),
                 torch.zeros(shape, dtype=torch.bfloat16, device=self.device))
 
-    def precompute_context(self, context: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        """context: [L<=text_len, text_dim] -> per-layer cross-attention (K, V) [num_layers, text_len, dim]."""
+    def precompute_context(self, context: torch.Tensor, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> CrossKV:
+        """context: [L<=text_len, text_dim] -> per-layer cross-attention K, V [num_layers, text_len, dim] as a `CrossKV` (unpacks as
+        (K, V); `.rows` = the leading rows that are distinct, see CrossKV).  `out`: write into these two buffers instead of new ones."""
         ctx = torch.zeros(self.text_len, self.text_dim, dtype=torch.bfloat16, device=self.device)
         ctx[:context.shape[0]] = context.to(device=self.device, dtype=torch.bfloat16)
-        ck = torch.empty(self.L, self.text_len, self.dim, dtype=torch.bfloat16, device=self.device)
-        cv = torch.empty_like(ck)
+        if out is None:
+            ck = torch.empty(self.L, self.text_len, self.dim, dtype=torch.bfloat16, device=self.device)
+            cv = torch.empty_like(ck)
+        else:
+            ck, cv = out
+            for t in (ck, cv):
+                assert t.shape == (self.L, self.text_len, self.dim) and t.dtype == torch.bfloat16 and t.is_contiguous() and t.device == self.device
         if self._ctx_ws is None:
             self._ctx_ws = torch.empty(self._lib.mmpl_dit_context_workspace_bytes(self._h), dtype=torch.uint8, device=self.device)
+        rows = C.c_int(self.text_len)
         with torch.cuda.device(self.device):          # the stream handed to the library is this device's current stream
             _lib.check(self._lib.mmpl_dit_precompute_context(self._h, _lib.ptr(ctx), _lib.ptr(ck), _lib.ptr(cv), _lib.ptr(self._ctx_ws),
-                                                             self._ctx_ws.numel(), _lib.stream_ptr()), "precompute_context")
-        return ck, cv
+                                                             self._ctx_ws.numel(), C.byref(rows), _lib.stream_ptr()), "precompute_context")
+        return CrossKV(ck, cv, rows.value)
 
     def precompute_image_context(self, clip_fea: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """clip_fea: [257, clip_dim] (CLIP ViT-H penultimate-block tokens, clip.py:541) -> per-layer image (K, V)
@@ -192,9 +218,12 @@ class DitEngine:
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, t: torch.Tensor, frame_ids: Sequence[int], write_slots: Sequence[int],
                 visible_slots: Sequence[int], k_cache: torch.Tensor, v_cache: torch.Tensor, cross_k: torch.Tensor,
-                cross_v: torch.Tensor, out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+                cross_v: torch.Tensor, out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
+                cross_rows: Optional[int] = None) -> torch.Tensor:
         """x: [nF, in_dim, lat_h, lat_w] bf16 (i2v: x and y concatenated on the channel axis); t: [nF] float32 (device).
         Returns the flow prediction [nF, 16, lat_h, lat_w].
+        `cross_rows`: the `CrossKV.rows` that belongs to the CONTENTS of cross_k / cross_v (rows cross_rows .. text_len-1 repeat one
+        row): the text cross-attention then runs over cross_rows + 1 keys.  None = attend over all text_len rows.
         `workspace`: a private scratch buffer (>= workspace_bytes(nF)) for a forward that runs concurrently with another
         one on a different stream (cond / uncond); default: the engine's own."""
         nF = x.shape[0]
@@ -210,13 +239,14 @@ class DitEngine:
         with torch.cuda.device(self.device):          # the stream handed to the library is this device's current stream
             _lib.check(self._lib.mmpl_dit_forward(
                 self._h, _lib.ptr(x), _lib.ptr(t), nF, ia(frame_ids), ia(write_slots), ia(visible_slots), len(visible_slots),
-                _lib.ptr(k_cache), _lib.ptr(v_cache), n_slots, _lib.ptr(cross_k), _lib.ptr(cross_v), _lib.ptr(out), _lib.ptr(ws),
+                _lib.ptr(k_cache), _lib.ptr(v_cache), n_slots, _lib.ptr(cross_k), _lib.ptr(cross_v),
+                self.text_len if cross_rows is None else int(cross_rows), _lib.ptr(out), _lib.ptr(ws),
                 ws.numel(), _lib.stream_ptr()), "mmpl_dit_forward")
         return out
 
     # ------------------------------------------------------------------ hipGraph
     def capture(self, x: torch.Tensor, t: torch.Tensor, frame_ids, write_slots, visible_slots, k_cache, v_cache, cross_k, cross_v,
-                out: torch.Tensor, pre=None) -> "torch.cuda.CUDAGraph":
+                out: torch.Tensor, pre=None, cross_rows: Optional[int] = None) -> "torch.cuda.CUDAGraph":
         """Capture one forward (fixed stage shape, slot table and buffers) into a hipGraph.  The forward is a pure launch
         sequence -- no host sync, no allocation -- so replaying it costs one graph launch instead of ~13 launches per
         layer.  `x`, `t`, `out` and the caches are captured BY ADDRESS: update their contents in place between replays
@@ -224,16 +254,16 @@ class DitEngine:
         `pre`: launches recorded in front of the forward (the i2v model type refreshes the latent channels of its 36-channel
         input buffer there)."""
         self.workspace(x.shape[0])                      # allocate outside the capture
-        if not getattr(self, "_warm", False):           # one eager call per engine: lazy kernel attributes are set outside
+        if not self._warm:                              # one eager call per engine: lazy kernel attributes are set outside
             if pre is not None:
                 pre()
-            self.forward(x, t, frame_ids, write_slots, visible_slots, k_cache, v_cache, cross_k, cross_v, out=out)
+            self.forward(x, t, frame_ids, write_slots, visible_slots, k_cache, v_cache, cross_k, cross_v, out=out, cross_rows=cross_rows)
             self._warm = True
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             if pre is not None:
                 pre()
-            self.forward(x, t, frame_ids, write_slots, visible_slots, k_cache, v_cache, cross_k, cross_v, out=out)
+            self.forward(x, t, frame_ids, write_slots, visible_slots, k_cache, v_cache, cross_k, cross_v, out=out, cross_rows=cross_rows)
         return g
 

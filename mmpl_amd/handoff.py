@@ -137,9 +137,21 @@ class ChunkHandoff:
     `poll()` between stages, `run_chunk_wavefront` drains with a blocking wait after the chunk).  Either way a send kernel is
     only ever launched against a recv that is already posted: it occupies one CU for the microseconds the 3.7 MB take.
     Chunk order makes the blocking drain deadlock-free: the wait is for the consumer to finish an EARLIER chunk.
-    `stats[c]` keeps wall-clock stamps (time.time(), one host) of every hand-off for bench.py's wavefront report."""
+    `stats[c]` keeps wall-clock stamps (time.time(), one host) of every hand-off for bench.py's wavefront report.
 
-    def __init__(self, shape: Sequence[int], device, group=None, ready_handshake: bool = True):
+    `control_timeout`: timeout of the gloo control group (default 12 h, the data path's own bound in mmpl_amd/cli.py): the
+    producer posts the receive of "ready for chunk c + 1" when ITS chunk starts and a waiter thread waits on it at once, so with
+    torch's 30-minute gloo default a consumer more than 30 minutes behind would abort a producer whose data path would have waited.
+    When the data group itself is gloo it is also the control group and carries whatever timeout its creator gave it.
+
+    `loopback` (single-rank self-test of the transport, tests/test_rccl_loopback_gpu.py): a hand-off whose consumer is this very
+    rank normally never touches the transport (`_local`); with loopback it goes through it -- a grouped send + recv to our own rank
+    on the side stream (RCCL runs that as a copy kernel), behind the same deferred-issue bookkeeping, with the gloo control group
+    created next to the RCCL group.  gloo has no pair to oneself, so the "ready" announcement is delivered in-process."""
+
+    def __init__(self, shape: Sequence[int], device, group=None, ready_handshake: bool = True, control_timeout=None,
+                 loopback: bool = False):
+        import datetime
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -155,8 +167,10 @@ class ChunkHandoff:
         self._ready_req = {}                   # consumer chunk -> irecv request of its "ready" announcement
         self._keep: List = []                  # control tensors / requests that must outlive their call
         self.stats = {}
-        self.handshake = ready_handshake and self.world > 1
+        self.loopback = bool(loopback) and self.world == 1
+        self.handshake = ready_handshake and (self.world > 1 or self.loopback)
         self._ctl = None
+        self._self_ready = {}                  # loopback: chunk -> threading.Event of our own announcement
         if self.handshake:
             # control plane: gloo.  The data group itself when it is gloo (CPU tests, shared-GPU functional runs); else a gloo
             # group over the same ranks, created by its members only (use_local_synchronization: non-members do not take part)
@@ -164,7 +178,8 @@ class ChunkHandoff:
                 self._ctl = group
             else:
                 ranks = [self._g(r) for r in range(self.world)]
-                self._ctl = dist.new_group(ranks, backend="gloo", use_local_synchronization=True)
+                self._ctl = dist.new_group(ranks, backend="gloo", use_local_synchronization=True,
+                                           timeout=control_timeout or datetime.timedelta(hours=12))
 
     def owner(self, chunk: int) -> int:
         return chunk % self.world
@@ -172,7 +187,12 @@ class ChunkHandoff:
     # ---- ready handshake (host side, gloo)
     def expect_ready(self, chunk: int) -> None:
         """Producer of `chunk - 1`: post the receive of the consumer's "ready for `chunk`" announcement (returns at once)."""
-        if not self.handshake or self.owner(chunk) == self.rank or chunk in self._ready_req:
+        if not self.handshake or chunk in self._ready_req:
+            return
+        import threading
+        if self.owner(chunk) == self.rank:
+            if self.loopback:                                  # our own announcement: an in-process Event (gloo has no self pair)
+                self._ready_req[chunk] = (None, None, self._self_ready.setdefault(chunk, threading.Event()), [])
             return
         buf = torch.zeros(1, dtype=torch.int64)
         req = self.dist.irecv(buf, self._g(self.owner(chunk)), group=self._ctl, tag=_READY_TAG + chunk)
@@ -180,7 +200,6 @@ class ChunkHandoff:
         # (measured: tools-free probe in profiles/NOTEBOOK_r04.md section J) -- polling it would defer every hand-off to the blocking
         # drain at the end of the producer's chunk and serialise the wavefront.  So a daemon thread does the waiting (Work.wait()
         # releases the GIL) and an Event carries the news to the non-blocking checks at the sink and at the stage boundaries.
-        import threading
         arrived, failed = threading.Event(), []
 
         def waiter():
@@ -197,19 +216,23 @@ class ChunkHandoff:
         """Consumer of `chunk`: tell the producer of chunk - 1 that the recv is about to be posted."""
         import time
         self.stats.setdefault(chunk, {})["t_ready"] = time.time()
+        if self.handshake and self.loopback and self.owner(chunk - 1) == self.rank:
+            import threading
+            self._self_ready.setdefault(chunk, threading.Event()).set()
+            return
         if not self.handshake or self.owner(chunk - 1) == self.rank:
             return
         buf = torch.tensor([chunk], dtype=torch.int64)
         self._keep.append((self.dist.isend(buf, self._g(self.owner(chunk - 1)), group=self._ctl, tag=_READY_TAG + chunk), buf))
 
-    def _consumer_ready(self, chunk: int, block: bool) -> bool:
+    def _consumer_ready(self, chunk: int, block: bool, timeout: Optional[float] = None) -> bool:
         if not self.handshake:
             return True
         if chunk not in self._ready_req:
             self.expect_ready(chunk)
         _, _, arrived, failed = self._ready_req[chunk]
         if block:
-            arrived.wait()
+            arrived.wait(timeout)
         if arrived.is_set() and failed:
             raise RuntimeError(f"hand-off: waiting for the consumer of chunk {chunk} to announce itself failed: {failed[0]}")
         return arrived.is_set()
@@ -218,6 +241,24 @@ class ChunkHandoff:
         import time
         dst = self._g(self.owner(chunk + 1))
         self.stats.setdefault(chunk + 1, {})["t_issued"] = time.time()
+        if self.loopback and self.owner(chunk + 1) == self.rank:
+            # to ourselves through the transport: sends and receives in ONE group call (an ungrouped send to oneself never meets its
+            # receive); the received copies are what recv() hands out
+            rh, rp = torch.zeros_like(hdr), torch.empty_like(payload)
+            P = self.dist.P2POp
+            ops = [P(self.dist.isend, hdr, dst, self.group), P(self.dist.irecv, rh, dst, self.group),
+                   P(self.dist.isend, payload, dst, self.group), P(self.dist.irecv, rp, dst, self.group)]
+            if self._side is not None:
+                self._side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(self._side):
+                    self._pending += self.dist.batch_isend_irecv(ops)
+                    for t in (hdr, payload, rh, rp):
+                        t.record_stream(self._side)
+            else:
+                self._pending += self.dist.batch_isend_irecv(ops)
+            self._keep.append((hdr, payload))
+            self._local = (rh, rp)
+            return
         if self._side is not None:
             self._side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self._side):
@@ -240,7 +281,7 @@ class ChunkHandoff:
         hdr = torch.tensor([status, chunk, int(now * 1e6)], dtype=torch.int64, device=self.device)
         payload = (torch.zeros(self.shape, dtype=torch.bfloat16, device=self.device) if tensor is None
                    else tensor.detach().to(device=self.device, dtype=torch.bfloat16).reshape(self.shape).contiguous())
-        if dst_local == self.rank:                             # world size 1 (or wrap onto ourselves): local hand-over
+        if dst_local == self.rank and not self.loopback:       # world size 1 (or wrap onto ourselves): local hand-over
             self._local = (hdr, payload)
             return
         if payload.data_ptr() == (tensor.data_ptr() if tensor is not None else 0):
@@ -261,12 +302,28 @@ class ChunkHandoff:
         self._deferred = still
         return len(still)
 
-    def drain(self) -> None:
-        """Blocking: wait for every deferred hand-off's consumer and issue it (end of the producer's chunk)."""
+    def drain(self, timeout: Optional[float] = None) -> None:
+        """Blocking: wait for every deferred hand-off's consumer and issue it (end of the producer's chunk).  A hand-off to
+        ourselves (loopback) stays deferred: its consumer is this thread, recv() issues it.  `timeout` (seconds per hand-off):
+        give up on a consumer that does not announce itself (error paths only) -- the entry is dropped, the peer's recv then
+        runs into the process group's own timeout."""
+        still = []
         for chunk, hdr, payload in self._deferred:
-            self._consumer_ready(chunk + 1, block=True)
-            self._issue(chunk, hdr, payload)
-        self._deferred = []
+            if self.loopback and self.owner(chunk + 1) == self.rank:
+                still.append((chunk, hdr, payload))
+                continue
+            if self._consumer_ready(chunk + 1, block=True, timeout=timeout):
+                self._issue(chunk, hdr, payload)
+        self._deferred = still
+
+    def fail_deferred(self, timeout: float = 600.0) -> None:
+        """The producer is about to raise with hand-offs still deferred (its consumer was busy at the sink and at every poll since):
+        they would be lost and the consumer would sit in recv until the process-group timeout.  Their status becomes FAILED -- the
+        video cannot be completed, the consumer must raise, not go on -- and they are issued as soon as the consumer announces
+        itself, waiting at most `timeout` seconds for that."""
+        for _, hdr, _ in self._deferred:
+            hdr[0] = FAILED
+        self.drain(timeout=timeout)
 
     def recv(self, chunk: int) -> torch.Tensor:
         """Receive the hand-off produced by chunk-1.  Blocks until the producer's anchor stage is done (minutes per lane at
@@ -277,6 +334,13 @@ class ChunkHandoff:
         src = self._g(src_local)
         self.announce_ready(chunk)
         if src_local == self.rank:
+            if self.loopback:                                   # our own deferred hand-off, through the transport, now that "we" are ready
+                self.poll()
+                for w in self._pending:
+                    w.wait()
+                self._pending.clear()
+                if self._side is not None:
+                    torch.cuda.current_stream(self.device).wait_stream(self._side)
             hdr, payload = self._local
         else:
             hdr = torch.zeros(3, dtype=torch.int64, device=self.device)
@@ -343,9 +407,16 @@ def run_chunk_wavefront(make_chunk: Callable[[int, Optional[torch.Tensor], Calla
                 raise RuntimeError(f"chunk {c} finished without producing its hand-off")
             handoff.drain()                                    # a consumer that was still busy at the sink and at every poll since
         except Exception:
-            if not sent[0] and c + 1 < n_chunks:
-                handoff.send(c, None, FAILED)                 # unblock the consumer with an error instead of a hang
-                handoff.flush()
+            if c + 1 < n_chunks:
+                try:
+                    if not sent[0]:
+                        handoff.send(c, None, FAILED)         # unblock the consumer with an error instead of a hang
+                    # ... and a hand-off the ready handshake deferred at the sink (sent[0] is True, nothing has left yet) must not
+                    # be lost either: it goes out marked FAILED as soon as the consumer announces itself
+                    handoff.fail_deferred()
+                    handoff.flush()
+                except Exception:                              # (the consumer may be gone as well: keep the ORIGINAL error)
+                    pass
             raise
     handoff.flush()
     if not gather:

@@ -57,6 +57,7 @@ class CrossAttnCache(list):
         self.engine = engine
         self.k_all = torch.zeros(engine.L, engine.text_len, engine.dim, dtype=torch.bfloat16, device=engine.device)
         self.v_all = torch.zeros_like(self.k_all)
+        self.rows = engine.text_len       # rows `rows .. text_len-1` of k_all / v_all repeat one row (CrossKV.rows of the contents)
         H = engine.cfg["num_heads"]
         for l in range(engine.L):
             self.append({"k": self.k_all[l].view(1, -1, H, 128), "v": self.v_all[l].view(1, -1, H, 128), "is_init": False})
@@ -66,9 +67,7 @@ class CrossAttnCache(list):
         return all(b["is_init"] for b in self)
 
     def fill(self, prompt_embeds: torch.Tensor):
-        ck, cv = self.engine.precompute_context(prompt_embeds)
-        self.k_all.copy_(ck)
-        self.v_all.copy_(cv)
+        self.rows = self.engine.precompute_context(prompt_embeds, out=(self.k_all, self.v_all)).rows
         for b in self:
             b["is_init"] = True
 
@@ -183,7 +182,7 @@ class WanFPSWrapper(torch.nn.Module):
             pre = lambda: x[:, :16].copy_(lat)
         g = self.engine.capture(x, timestep.view(-1), frames, StagePlan.write_slots(frames),
                                 [slot_of(o // S) for o in vis], kv_cache.k_all, kv_cache.v_all, crossattn_cache.k_all,
-                                crossattn_cache.v_all, out[0], pre=pre)
+                                crossattn_cache.v_all, out[0], pre=pre, cross_rows=crossattn_cache.rows)
         return g if ys is None else _HeldGraph(g, x)
 
     def forward(self, noisy_image_or_video: torch.Tensor, conditional_dict: dict, timestep: torch.Tensor,
@@ -213,7 +212,7 @@ class WanFPSWrapper(torch.nn.Module):
         t = timestep.reshape(-1).to(device=x.device, dtype=torch.float32)
         flow = self.engine.forward(x, t, frames, StagePlan.write_slots(frames), [slot_of(o // S) for o in vis],
                                    kv_cache.k_all, kv_cache.v_all, crossattn_cache.k_all, crossattn_cache.v_all,
-                                   out=None if out is None else out[0])
+                                   out=None if out is None else out[0], cross_rows=crossattn_cache.rows)
         flow_pred = flow.unsqueeze(0)
         pred_x0 = None
         if return_x0:                                                     # wan_wrapper.py:373-397 (unused by the pipeline)

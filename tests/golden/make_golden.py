@@ -1,7 +1,7 @@
 """Generate golden fixtures by running the REAL reference (/root/reference, CPU, bf16) on seeded inputs.
 
 Build-container only (the reference never travels to the GPU box).  Usage:
-    python tests/golden/make_golden.py [dit] [chunk] [chunk50] [chunk50_gpu] [sched] [vae]
+    python tests/golden/make_golden.py [dit] [chunk] [chunk50] [chunk50_gpu] [chunk_i2v] [chunk_i2v50] [sched] [vae]
 Writes tests/golden/*.pt.  Inputs are regenerated from seeds by the tests (mmpl_amd.synthetic), so the
 fixtures hold expected OUTPUTS of the reference (full or strided + sha256), plus known-answer scalars.
 While generating, the oracle restatement (oracle/) is run on the same inputs and its agreement with the
@@ -147,23 +147,73 @@ def gen_chunk(steps=2):
                os.path.join(HERE, "chunk_t2v_tiny.pt"))
 
 
-def _ref_stage_loop(m, fps, unipc, sched, cfg, noise, renoise, ctxs, steps, dtype=torch.bfloat16, progress=None):
-    """casual_fps_inference.py:250-403 re-enacted on the reference model + the reference UniPC, `steps` per stage."""
+class _GpuScalar(torch.Tensor):
+    """The reference's UniPC step under the scalar semantics of its NATIVE platform, without editing the reference.
+
+    `FlowUniPCMultistepScheduler` keeps `sigmas` on the CPU (fm_solvers_unipc.py:129,226) and writes its scalar-tensor products
+    scalar-first (`sigma_t * model_output` :321, `sigma_t / sigma_s0 * x - alpha_t * h_phi_1 * m0` :460,600, `alpha_t * B_h * ...`
+    :466,607).  PyTorch's GPU kernels take a 0-dim fp32 CPU tensor as an fp32 scalar on either side of a multiply; its CPU kernels
+    round it to the tensor's dtype (bf16) when it is the FIRST operand and keep it in fp32 when it is the second.  Assigning
+    `scheduler.sigmas = scheduler.sigmas.as_subclass(_GpuScalar)` makes every scalar derived from `sigmas` carry this class, and
+    `__torch_function__` then does ONE thing: when a 0-dim fp32 tensor is the first operand of a multiply whose second operand is a
+    non-fp32 tensor with dims, the operands are swapped.  Everything else runs the reference's own code on plain tensors.  fp32
+    results of at most one dim are re-wrapped so that the property follows `sigma -> alpha, lambda, h, h_phi_1, B_h ...`."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        plain = lambda a: a.as_subclass(torch.Tensor) if isinstance(a, _GpuScalar) else a
+        args = tuple(plain(a) for a in args)
+        kwargs = {k: plain(v) for k, v in kwargs.items()}
+        if (getattr(func, "__name__", "") in ("mul", "__mul__") and len(args) == 2 and isinstance(args[0], torch.Tensor)
+                and args[0].dim() == 0 and args[0].dtype == torch.float32 and isinstance(args[1], torch.Tensor)
+                and args[1].dim() > 0 and args[1].dtype != torch.float32):
+            func, args = torch.mul, (args[1], args[0])
+        with torch._C.DisableTorchFunctionSubclass():
+            out = func(*args, **kwargs)
+        if isinstance(out, torch.Tensor) and out.dtype == torch.float32 and out.dim() <= 1:
+            out = out.as_subclass(_GpuScalar)
+        return out
+
+
+def _ref_stage_loop(m, fps, unipc, sched, cfg, noise, renoise, ctxs, steps, dtype=torch.bfloat16, progress=None,
+                    mode="t2v", initial_latent=None, gpu_scalars=False):
+    """The stage loop re-enacted on the reference model + the reference UniPC, `steps` per stage.
+    t2v: MMPL_t2v/pipeline/casual_fps_inference.py:250-403 (first chunk: re-noise of frames 4/9 and 13/18, frames 19/20 hidden
+    during stage 2 and re-added for stage 3, hand-off `cat([output[:, :1], latents])` after stage 1).
+    i2v: MMPL_i2v/pipeline/casual_fps_inference.py:253-435: schedule [0],[1],anchors,[4..9],[13..18]; `initial_latent` of one
+    frame (:403-435: refresh of stage 0, stage 1 is denoised) or two frames (:369-401: both refreshed, denoising starts at the
+    anchors); no re-noise, nothing hidden; hand-off `cat([output[:, :1], output[:, -2:]])` after the anchor stage (:340-343).
+    gpu_scalars: the scheduler's `sigmas` carry `_GpuScalar` (the reference's own step code under GPU scalar semantics)."""
     kvs = [ref_caches(cfg), ref_caches(cfg)]
     if dtype != torch.bfloat16:
         for kv, _ in kvs:
             for blk in kv:
                 blk["k"], blk["v"] = blk["k"].to(dtype), blk["v"].to(dtype)
     noise = noise.to(dtype)
-    stages = stage_ref.stage_frames(stage_ref.T2V_CLEAN_STEPS)
+    stages = stage_ref.stage_frames(stage_ref.T2V_CLEAN_STEPS if mode == "t2v" else stage_ref.I2V_CLEAN_STEPS)
     output = torch.zeros_like(noise)
     handoff = None
     fm = sched.FlowMatchScheduler(shift=5.0, sigma_min=0.0, extra_one_step=True)
     fm.set_timesteps(1000, training=True)
     ddmp_t = torch.tensor([[1980.0]])                  # timesteps[idx]+1000 >= 1000 for any idx (pipeline :96-107)
-    for si, frames in enumerate(stages):
+
+    def refresh(latents, frames):
+        for w in (0, 1):
+            ref_forward(m, latents, 0.0, ctxs[w], kvs[w][0], kvs[w][1], frames)
+
+    first = 0
+    if mode == "i2v":
+        assert initial_latent is not None and initial_latent.shape[1] in (1, 2)
+        initial_latent = initial_latent.to(dtype)
+        for j in range(initial_latent.shape[1]):       # i2v :369-435
+            refresh(initial_latent[:, j:j + 1], stages[j])
+            output[:, stages[j]] = initial_latent[:, j:j + 1]
+        first = initial_latent.shape[1]
+    for si in range(first, len(stages)):
+        frames = stages[si]
         latents = noise[:, frames]
-        if si in (2, 3):
+        if mode == "t2v" and si in (2, 3):
             src = (3, 10) if si == 2 else (12, 19)
             latents[:, 0:1] = fm.add_noise(output[:, src[0]:src[0] + 1].flatten(0, 1), renoise[frames[0]].to(dtype),
                                            ddmp_t.flatten(0, 1)).unflatten(0, (1, 1))
@@ -178,16 +228,20 @@ def _ref_stage_loop(m, fps, unipc, sched, cfg, noise, renoise, ctxs, steps, dtyp
                             blk["attention_vis_index"].append(v)
         s = unipc.FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
         s.set_timesteps(steps, device="cpu", shift=5.0)
+        if gpu_scalars:
+            s.sigmas = s.sigmas.as_subclass(_GpuScalar)
         for t in s.timesteps:
             fc = ref_forward(m, latents, t, ctxs[0], kvs[0][0], kvs[0][1], frames)
             fu = ref_forward(m, latents, t, ctxs[1], kvs[1][0], kvs[1][1], frames)
             flow = fu + 5.0 * (fc - fu)
             latents = s.step(flow, t, latents, return_dict=False)[0]
+            assert type(latents) is torch.Tensor and latents.dtype == dtype
         output[:, frames] = latents
-        if si == 1:
+        if mode == "t2v" and si == 1:
             handoff = torch.cat([output[:, :1], latents], dim=1)
-        for w in (0, 1):
-            ref_forward(m, latents, 0.0, ctxs[w], kvs[w][0], kvs[w][1], frames)
+        if mode == "i2v" and si == 2:
+            handoff = torch.cat([output[:, :1], output[:, -2:]], dim=1)
+        refresh(latents, frames)
         if progress:
             progress(si)
     return output, handoff
@@ -255,32 +309,105 @@ def gen_chunk50(steps=50):
                os.path.join(HERE, "chunk_t2v_tiny_50.pt"))
 
 
-def gen_chunk50_gpu_semantics(steps=50):
-    """The same 408-forward chunk under the scalar semantics of the reference's NATIVE platform.  The committed chunk50 fixture is
-    the reference run on a CPU, where PyTorch rounds the UniPC step's 0-dim fp32 scalars to bf16 when they are the first operand of
-    a multiply (`sigma_t * x`, fm_solvers_unipc.py:315-331 and the predictor / corrector updates); its GPU kernels keep them in fp32
-    (oracle/unipc_ref.py).  The reference's scheduler source cannot be made to multiply tensor-first without editing it, so this
-    fixture is produced by the ORACLE (bit-exact to the reference forward by forward, 6.3e-3 = the reference's own order noise from
-    it after 408 forwards with the switch off -- chunk50 above) with `gpu_scalar_semantics=True`: nothing but the operand order of
-    those scalar products changes.  Stored with it: its distance to the CPU-semantics fixture (2.3e-2: what the platform alone
-    does to the trajectory) and to the reference's fp32 run (1.6e-2: the GPU semantics are the more accurate ones)."""
-    fx = torch.load(os.path.join(HERE, "chunk_t2v_tiny_50.pt"))
-    m = fx["meta"]
+def _chunk_inputs(m):
     cfg = WAN_CONFIGS[m["cfg"]]
-    sd = dit_state_dict(cfg, seed=m["weight_seed"])
-    ctxs = [make_context(cfg, s_, nv)[0] for s_, nv in zip(m["ctx_seeds"], m["n_valid"])]
+    ctxs = [make_context(cfg, s_, nv) for s_, nv in zip(m["ctx_seeds"], m["n_valid"])]
     noise = philox_normal([1, 21, 16, H, Wd], m["noise_seed"])
     renoise = {f: philox_normal([1, 16, H, Wd], m["renoise_seed_base"] + f) for f in (4, 9, 13, 18)}
+    return cfg, ctxs, noise, renoise
+
+
+def gen_chunk50_gpu_semantics(steps=50):
+    """The same 408-forward chunk under the scalar semantics of the reference's NATIVE platform, produced by the REAL reference.
+    The committed chunk50 fixture is the reference run on a CPU, where PyTorch rounds the UniPC step's 0-dim fp32 scalars to bf16
+    when they are the first operand of a multiply (`sigma_t * x`, fm_solvers_unipc.py:315-331 and the predictor / corrector
+    updates :460-476,600-618); its GPU kernels keep them in fp32.  Here the reference's own `FlowUniPCMultistepScheduler.step`
+    runs with `sigmas` carrying `_GpuScalar` (above): unedited reference code, only the operand order of those products swapped at
+    dispatch.  First the shim is checked on the toy trajectory of `gen_sched` against `FlowUniPCRef(gpu_scalar_semantics=True)`
+    (bit-exact).  Stored with the reference's output: its distance to the CPU-semantics fixture (what the platform alone does to the
+    trajectory), to the reference's fp32 run, and -- as a cross-check only -- the oracle's `gpu_scalar_semantics=True` run."""
+    fps, _, _, _, unipc, sched = load_reference()
+    _check_gpu_scalar_shim(unipc)
+    fx = torch.load(os.path.join(HERE, "chunk_t2v_tiny_50.pt"))
+    m = fx["meta"]
+    assert m["steps"] == steps
+    cfg, ctxs, noise, renoise = _chunk_inputs(m)
+    mdl, sd, _ = build_ref_model(fps, m["cfg"], seed=m["weight_seed"])
     t0 = time.time()
-    out, hand, _ = stage_ref.run_chunk(sd, W.DitCfg(**cfg), noise, ctxs[0], ctxs[1], renoise, None, "t2v", m["guidance"], steps, m["shift"],
-                                       gpu_scalar_semantics=True)
+    tick = lambda si: print(f"[chunk50_gpu] reference, GPU scalar semantics: stage {si} done at {time.time() - t0:.0f}s", flush=True)
+    out, hand = _ref_stage_loop(mdl, fps, unipc, sched, cfg, noise.clone(), renoise, ctxs, steps, progress=tick, gpu_scalars=True)
     d = dict(vs_cpu_semantics_out=rel_l2(out[..., ::2, ::2], fx["out_strided"]), vs_cpu_semantics_handoff=rel_l2(hand[..., ::3, ::3], fx["handoff_strided"]),
              vs_f32_out=rel_l2(out[..., ::2, ::2], fx["out_f32_strided"]))
-    print(f"[chunk50_gpu] oracle, GPU scalar semantics: {time.time() - t0:.1f}s  vs the reference's CPU run: out={d['vs_cpu_semantics_out']:.3e} "
-          f"handoff={d['vs_cpu_semantics_handoff']:.3e}; vs the reference's fp32 run: {d['vs_f32_out']:.3e}", flush=True)
+    print(f"[chunk50_gpu] REFERENCE under GPU scalar semantics: {time.time() - t0:.1f}s  vs its CPU-semantics run: out={d['vs_cpu_semantics_out']:.3e} "
+          f"handoff={d['vs_cpu_semantics_handoff']:.3e}; vs its fp32 run: {d['vs_f32_out']:.3e}", flush=True)
+    t0 = time.time()
+    o_out, o_hand, _ = stage_ref.run_chunk(sd, W.DitCfg(**cfg), noise, ctxs[0][0], ctxs[1][0], renoise, None, "t2v", m["guidance"], steps, m["shift"],
+                                           gpu_scalar_semantics=True)
+    d.update(oracle_out=rel_l2(o_out, out), oracle_handoff=rel_l2(o_hand, hand))
+    print(f"[chunk50_gpu] oracle(gpu_scalar_semantics=True): {time.time() - t0:.1f}s  vs the reference under the shim: out={d['oracle_out']:.3e} "
+          f"handoff={d['oracle_handoff']:.3e} (the reference's own K/V-order noise: {fx['noise_floor']['order_out']:.3e})", flush=True)
     torch.save(dict(out_sha=sha(out), out_strided=out[..., ::2, ::2].clone(), handoff_sha=sha(hand), handoff_strided=hand[..., ::3, ::3].clone(),
-                    distances=d, produced_by="oracle/stage_ref.run_chunk(gpu_scalar_semantics=True); see make_golden.py gen_chunk50_gpu_semantics",
+                    distances=d, oracle_out_sha=sha(o_out),
+                    produced_by="the REAL reference (CausalFPSWanModel + FlowUniPCMultistepScheduler.step, unedited) with scheduler.sigmas carrying "
+                                "make_golden._GpuScalar; see make_golden.py gen_chunk50_gpu_semantics",
                     meta=dict(m)), os.path.join(HERE, "chunk_t2v_tiny_50_gpu_semantics.pt"))
+
+
+def _check_gpu_scalar_shim(unipc):
+    """The shim on the toy trajectory: reference + `_GpuScalar` == FlowUniPCRef(gpu_scalar_semantics=True), bit for bit, and it differs
+    from the plain CPU run (else the shim did nothing)."""
+    dt = torch.bfloat16
+    x, target = philox_normal([1, 3, 4, 6, 8], 5, dt), philox_normal([1, 3, 4, 6, 8], 6, dt)
+    res = {}
+    for shim in (False, True):
+        s = unipc.FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+        s.set_timesteps(50, device="cpu", shift=5.0)
+        if shim:
+            s.sigmas = s.sigmas.as_subclass(_GpuScalar)
+        o = unipc_ref.FlowUniPCRef(1000, 2, 1.0, gpu_scalar_semantics=shim)
+        o.set_timesteps(50, shift=5.0)
+        xr, xo, traj = x.clone(), x.clone(), []
+        for i, t in enumerate(s.timesteps):
+            xr = s.step((xr - target) * (1.0 + 0.1 * torch.sin(xr.float() * 3 + i).to(dt)), t, xr, return_dict=False)[0]
+            xo = o.step((xo - target) * (1.0 + 0.1 * torch.sin(xo.float() * 3 + i).to(dt)), xo)
+            assert torch.equal(xr, xo), (shim, i)
+            traj.append(xr.clone())
+        res[shim] = torch.stack(traj)
+    dmax = (res[True].float() - res[False].float()).abs().max().item()
+    assert dmax > 1e-2, dmax
+    print(f"[shim] reference + _GpuScalar == oracle(gpu_scalar_semantics=True) bit-exactly over 50 steps; vs the plain CPU run max|d| = {dmax:.3e}")
+    return res[True]
+
+
+def gen_chunk_i2v(steps=2, tag=""):
+    """The I2V stage plan (BASELINE configs[4]) from the REAL reference: MMPL_i2v/pipeline/casual_fps_inference.py:253-435 re-enacted on
+    the reference model (the I2V pipeline drives the same CausalFPSWanModel / UniPC sources: the two trees' files are identical up to
+    blank lines) for a first chunk (`initial_latent` = the image latent, 1 frame: stage [1] and the anchors are denoised) and for a
+    later chunk (2 frames, both refreshed, denoising starts at the anchors).  Under CPU scalar semantics (the reference as is) and,
+    for the tight HIP bound, under `_GpuScalar`."""
+    fps, _, _, _, unipc, sched = load_reference()
+    _check_gpu_scalar_shim(unipc)
+    m = dict(cfg="tiny", weight_seed=2, ctx_seeds=(21, 22), n_valid=(40, 12), noise_seed=24, renoise_seed_base=100, steps=steps,
+             guidance=5.0, shift=5.0, initial_seed=56)
+    cfg, ctxs, noise, _ = _chunk_inputs(m)
+    mdl, sd, _ = build_ref_model(fps, m["cfg"], seed=m["weight_seed"])
+    init2 = philox_normal([1, 2, 16, H, Wd], m["initial_seed"])
+    out = dict(meta=m, produced_by="the REAL reference (CausalFPSWanModel + FlowUniPCMultistepScheduler) driven through the I2V stage plan; "
+                                   "make_golden.py gen_chunk_i2v")
+    for n_init in (1, 2):
+        init = init2[:, :n_init]
+        for gpu in (False, True):
+            t0 = time.time()
+            o, h = _ref_stage_loop(mdl, fps, unipc, sched, cfg, noise.clone(), None, ctxs, steps, mode="i2v", initial_latent=init, gpu_scalars=gpu)
+            oo, oh, _ = stage_ref.run_chunk(sd, W.DitCfg(**cfg), noise, ctxs[0][0], ctxs[1][0], None, init, "i2v", m["guidance"], steps, m["shift"],
+                                            gpu_scalar_semantics=gpu)
+            key = f"init{n_init}_{'gpu' if gpu else 'cpu'}"
+            print(f"[chunk_i2v{tag}] {key}: {time.time() - t0:.1f}s  oracle-vs-ref out={rel_l2(oo, o):.3e} handoff={rel_l2(oh, h):.3e} "
+                  f"rms={o.float().pow(2).mean().sqrt().item():.3f}", flush=True)
+            assert torch.equal(o[:, :n_init], init) and h.shape == (1, 3, 16, H, Wd)
+            out[key] = dict(out_sha=sha(o), out_strided=o[..., ::4, ::2].clone(), handoff_sha=sha(h), handoff_strided=h[..., ::3, ::3].clone(),
+                            oracle_out=rel_l2(oo, o), oracle_handoff=rel_l2(oh, h))      # out_strided: rows ::4, columns ::2
+    torch.save(out, os.path.join(HERE, f"chunk_i2v_tiny{tag}.pt"))
 
 
 def gen_sched():
@@ -309,6 +436,8 @@ def gen_sched():
             traj.append(xr.clone())
         print(f"[sched] {name}: oracle-vs-ref max|d| = {(xo.float() - xr.float()).abs().max().item():.3e}")
         out[f"traj_{name}"] = torch.stack(traj)
+    # the same bf16 toy trajectory from the REAL scheduler under the scalar semantics of its native platform (`_GpuScalar`)
+    out["traj_bf16_gpu_semantics"] = _check_gpu_scalar_shim(unipc)
     fm = sched.FlowMatchScheduler(shift=5.0, sigma_min=0.0, extra_one_step=True)
     fm.set_timesteps(1000, training=True)
     of = unipc_ref.FlowMatchRef(5.0, 1000)
@@ -334,6 +463,10 @@ if __name__ == "__main__":
         gen_chunk50()
     if "chunk50_gpu" in what:
         gen_chunk50_gpu_semantics()
+    if "chunk_i2v" in what:
+        gen_chunk_i2v()
+    if "chunk_i2v50" in what:
+        gen_chunk_i2v(50, "_50")
     if "vae" in what:
         from make_golden_vae import gen_vae
         gen_vae()

@@ -24,16 +24,38 @@ def _run(extra):
     return json.loads(lines[0])
 
 
-def test_two_chunk_lanes():
-    r = _run([])
-    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and "functional_only" in r
+def test_default_two_rank_line_is_a_measured_wavefront():
+    """`bench.py --gpus 2` with NO wavefront flag runs one video of 2 x lanes chunks through the real pipeline
+    and the real dependency chain and reports its wall clock; the UniPC steps per stage come from the wall-clock budget and the
+    scaling to the reference's 50 steps is stated; the occupancy model is printed beside it, not as `value`."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--model", "tiny", "--res", "tiny",
+           "--wavefront-budget-s", "20", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["lanes"] == 2 and r["chunks"] == 4 and r["config"]["parallelism"].startswith("measured wavefront")
+    k = r["config"]["sampling_steps"]
+    assert 2 <= k <= 50 and r["value_modelled"] > 0 and r["ms_per_step"] > 0
+    if k < 50:
+        assert abs(r["value_shortened_run"] - 21.0 * 4 / r["wall_s"]) < 1e-9 and "value_scaling" in r
+        assert abs(r["value"] - r["value_shortened_run"] * (2 * k + 2) / 102.0) < 1e-9
+    else:
+        assert abs(r["value"] - 21.0 * 4 / r["wall_s"]) < 1e-9
+
+
+def test_two_chunk_lanes_rotation_line():
+    r = _run(["--rotation"])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and "functional_only" in r and "value_is_modelled" in r
     assert "chunk-per-rank x2" in r["config"]["parallelism"] and "hand-off" in r["config"]["parallelism"]
     assert r["value"] > 0 and r["value_independent_chunks"] >= r["value"] and len(r["sec_per_denoise_step_by_stage"]) == 4
     assert r["roofline"]["achieved"] > 0
 
 
 def test_cfg_pair_with_graphed_forwards():
-    r = _run(["--cfg-split"])
+    r = _run(["--cfg-split", "--rotation"])
     assert r["n_gpus"] == 2 and "CFG split" in r["config"]["parallelism"]
     assert "hipGraph replay per forward" in r["config"]["timed_path"]
     assert r["value"] > 0 and r["roofline"]["achieved"] > 0
@@ -57,7 +79,8 @@ def test_measured_wavefront_two_lanes():
     chunk c's anchors), wall clock first noise -> last latent; two ranks on one GPU over gloo (functional)."""
     r = _wavefront(2, [])
     assert r["n_gpus"] == 2 and r["chunks"] == 4 and r["lanes"] == 2 and "measured wavefront" in r["config"]["parallelism"]
-    assert abs(r["value"] - 21.0 * 4 / r["wall_s"]) < 1e-9 and r["value_modelled"] > 0
+    assert abs(r["value_shortened_run"] - 21.0 * 4 / r["wall_s"]) < 1e-9 and r["value_modelled"] > 0
+    assert abs(r["value"] - r["value_shortened_run"] * 8.0 / 102.0) < 1e-9           # 3 steps: (2 * 3 + 2) / 102 of the full length
     assert len(r["chunk_s"]) == 4 and len(r["stagger_s"]) == 3 and all(s > 0 for s in r["stagger_s"])
     # chunk c + 1 cannot start before chunk c's anchor stage is done (the dependency is real)
     assert all(st >= a - 0.05 for st, a in zip(r["stagger_s"], r["anchor_done_after_s"]))
@@ -68,7 +91,7 @@ def test_measured_wavefront_two_lanes():
     assert r["stagger_s"][0] < 0.9 * r["chunk_s"][0], (r["stagger_s"], r["chunk_s"])
     assert set(r["rank_busy_fraction"]) == {"0", "1"} and all(0 < v <= 1.0 for v in r["rank_busy_fraction"].values())
     assert set(r["handoff_latency_s"]) == {"1", "2", "3"} and all(0 <= v < 30 for v in r["handoff_latency_s"].values())
-    assert "not_the_metric" in r and "functional_only" in r          # 3 sampling steps, shared GPU
+    assert "value_scaling" in r and "functional_only" in r          # 3 sampling steps, shared GPU
 
 
 def test_measured_wavefront_one_rank_is_the_sequential_chain():
@@ -83,7 +106,7 @@ def test_measured_wavefront_two_lanes_of_cfg_pairs():
     is measured the same way."""
     r = _wavefront(4, ["--cfg-split"])
     assert r["n_gpus"] == 4 and r["chunks"] == 4 and r["lanes"] == 2 and "measured wavefront" in r["config"]["parallelism"]
-    assert abs(r["value"] - 21.0 * 4 / r["wall_s"]) < 1e-9
+    assert abs(r["value_shortened_run"] - 21.0 * 4 / r["wall_s"]) < 1e-9
     assert len(r["stagger_s"]) == 3 and all(st >= a - 0.05 for st, a in zip(r["stagger_s"], r["anchor_done_after_s"]))
     # (checked on the first hand-off: later staggers on 2 lanes include waiting for the lane to finish its previous chunk, and chunk 0
     # carries the one-time graph captures)

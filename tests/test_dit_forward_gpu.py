@@ -172,11 +172,12 @@ def test_build_then_smoke_in_one_process():
 @pytest.mark.parametrize("n_valid", [0, 1, 37, 63, 64, 65, 448, 510, 511, 512])
 def test_cross_attention_padded_tail_collapse(n_valid):
     """The zero-padded tail of the text context is ONE repeated K / V row after the text embedding (utils/wan_wrapper.py:46-47 zeroes
-    it, causal_fps_model.py:780 / model.py:189 attend over it unmasked): the forward attends over n_valid + 1 keys with the last one
-    weighted 512 - n_valid times (api.hip).  Same forward through a cross cache the engine does NOT know to collapse (a copy at
-    another address: all 512 keys) -- equal up to the bf16 rounding of the padded key's P entry (bf16(c * p) vs c * bf16(p): up to
-    2 * 2^-9 of that key's share of the output, which is nearly all of it when n_valid is 0 or 1); n_valid >= 511 leaves nothing
-    to collapse."""
+    it, causal_fps_model.py:780 / model.py:189 attend over it unmasked): a forward that is TOLD so (`cross_rows` = the count
+    mmpl_dit_precompute_context reported for these contents) attends over n_valid + 1 keys with the last one weighted 512 - n_valid
+    times (api.hip).  The count is explicit data (it used to be remembered per cross_k POINTER): the same forward without
+    it attends over all 512 keys -- equal up to the bf16 rounding of the padded key's P entry (bf16(c * p) vs c * bf16(p): up to
+    2 * 2^-9 of that key's share of the output, which is nearly all of it when n_valid is 0 or 1); a COPY of the K / V with the
+    count handed on gives the collapsed bits; n_valid >= 511 leaves nothing to collapse."""
     from mmpl_amd.dit import DitEngine
     from mmpl_amd.synthetic import WAN_CONFIGS, dit_state_dict, philox_normal
     cfg = WAN_CONFIGS["tiny"]
@@ -184,7 +185,9 @@ def test_cross_attention_padded_tail_collapse(n_valid):
     eng.load_state_dict(dit_state_dict(cfg, seed=3))
     ctx = philox_normal([512, cfg["text_dim"]], 40 + n_valid)
     ctx[n_valid:] = 0
-    ck, cv = eng.precompute_context(ctx.cuda())
+    kv = eng.precompute_context(ctx.cuda())
+    ck, cv = kv
+    assert kv.rows == (n_valid if n_valid < 511 else 512), (kv.rows, n_valid)
     ck2, cv2 = ck.clone(), cv.clone()
     # the padded K / V rows really are one row (what the collapse relies on), in every layer
     if n_valid < 511:
@@ -193,15 +196,38 @@ def test_cross_attention_padded_tail_collapse(n_valid):
     x = philox_normal([2, 16, 16, 24], 7).cuda()
     t = torch.full([2], 700.0, dtype=torch.float32).cuda()
     outs = []
-    for k_, v_ in ((ck, cv), (ck2, cv2)):
+    for k_, v_, rows in ((ck, cv, kv.rows), (ck2, cv2, None), (ck2, cv2, kv.rows), (ck, cv, 512)):
         kc, vc = eng.new_kv_cache(15)
-        outs.append(eng.forward(x, t, frames, [0, 1], [0, 1], kc, vc, k_, v_).clone())
+        outs.append(eng.forward(x, t, frames, [0, 1], [0, 1], kc, vc, k_, v_, cross_rows=rows).clone())
     torch.cuda.synchronize()
     e = rel_l2(outs[0], outs[1])
     print(f"n_valid {n_valid}: rel_l2(collapsed, all 512 keys) = {e:.3e}")
     assert torch.isfinite(outs[0].float()).all() and e < 4e-3
+    assert torch.equal(outs[0], outs[2])           # the count travels with the contents, not with the address
+    assert torch.equal(outs[1], outs[3])           # no count / text_len: all 512 keys, whichever buffer
     if n_valid >= 511:
         assert torch.equal(outs[0], outs[1])
+
+
+def test_cross_attn_cache_takes_the_collapsed_path_like_the_bench():
+    """`CrossAttnCache.fill` used to register a temporary and copy it, so the pipeline never got the
+    collapse the bench measured.  Now precompute writes straight into the cache's buffers and the cache carries `rows`."""
+    from mmpl_amd.dit import DitEngine
+    from mmpl_amd.synthetic import WAN_CONFIGS, dit_state_dict, philox_normal
+    from mmpl_amd.wan_wrapper import CrossAttnCache
+    cfg = WAN_CONFIGS["tiny"]
+    eng = DitEngine(cfg, 16, 24, "cuda:0")
+    eng.load_state_dict(dit_state_dict(cfg, seed=3))
+    ctx = philox_normal([512, cfg["text_dim"]], 77)
+    ctx[48:] = 0
+    cache = CrossAttnCache(eng)
+    assert cache.rows == 512 and not cache.is_init
+    cache.fill(ctx.cuda())
+    kv = eng.precompute_context(ctx.cuda())
+    assert cache.is_init and cache.rows == 48 == kv.rows
+    assert torch.equal(cache.k_all, kv[0]) and torch.equal(cache.v_all, kv[1])
+    cache.fill(philox_normal([512, cfg["text_dim"]], 78).cuda())        # a full-length prompt into the SAME buffers: the stale count must go
+    assert cache.rows == 512
 
 
 def test_forward_bits_do_not_depend_on_where_the_workspace_lies():

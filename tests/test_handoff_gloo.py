@@ -144,3 +144,95 @@ def test_ready_handshake_defers_sends_until_the_consumer_announced(tmp_path):
         for c in chunks:
             st = r["stats"][c]
             assert st["t_ready"] <= st["t_recv_done"] and st["t_sink"] <= st["t_recv_done"] + 1e-3, (c, st)
+
+
+def _late_fail_worker(rank, world, port, out_path):
+    """Rank 1's chunk 1 reaches its sink while rank 0 is still inside chunk 0 (hand-off DEFERRED by the ready handshake), then fails
+    in a later stage: the deferred anchors must not be lost -- rank 0's recv for chunk 2 has to raise, not hang."""
+    import datetime
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    ho = ChunkHandoff(SHAPE, "cpu")
+    seen = {}
+
+    def make_chunk(c, initial, sink):
+        base = torch.full(SHAPE, float(c + 1), dtype=torch.bfloat16)
+        time.sleep(0.1)
+        sink(base)
+        seen[c] = len(ho._deferred)
+        if c == 0:
+            time.sleep(1.5)                    # rank 0 stays busy long after its sink: chunk 1's hand-off finds it not ready
+        if c == 1:
+            time.sleep(0.2)
+            raise ValueError("late boom")      # after the sink, with the hand-off still deferred
+        return base[:, :2].clone()
+
+    t0 = time.time()
+    try:
+        run_chunk_wavefront(make_chunk, 4, ho, to_initial=lambda t: t[:, :2])
+        err = None
+    except Exception as e:
+        err = repr(e)
+        time.sleep(2)
+    torch.save({"err": err, "seen": seen, "secs": time.time() - t0}, f"{out_path}.{rank}")
+    dist.destroy_process_group()
+
+
+def test_deferred_handoff_of_a_producer_that_fails_later_is_not_lost(tmp_path):
+    out = str(tmp_path / "lf")
+    mp.spawn(_late_fail_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = (torch.load(f"{out}.{r}") for r in range(2))
+    assert "late boom" in r1["err"] and r1["seen"].get(1) == 1, r1          # it WAS deferred when the producer failed
+    assert r0["err"] is not None and "status -1" in r0["err"], r0           # the consumer got the FAILED header ...
+    assert r0["secs"] < 30                                                   # ... promptly, not at the 60 s group timeout
+
+
+def _six_chunk_worker(rank, world, port, out_path, stage_s):
+    """n_chunks = 3 x lanes with equal chunks of 4 'stages' (sink after the 2nd, a poll at every stage boundary, as the pipeline does)."""
+    import datetime
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    ho = ChunkHandoff(SHAPE, "cpu")
+    marks = {}
+
+    def make_chunk(c, initial, sink):
+        base = torch.full(SHAPE, float(c + 1), dtype=torch.bfloat16)
+        marks[c] = {"t_start": time.time()}
+        for st in range(4):
+            time.sleep(stage_s)
+            if st == 1:
+                sink(base)
+            ho.poll()
+        marks[c]["t_end"] = time.time()
+        return base[:, :2].clone()
+
+    run_chunk_wavefront(make_chunk, 3 * world, ho, to_initial=lambda t: t[:, :2], gather=False)
+    torch.save({"stats": ho.stats, "marks": marks}, f"{out_path}.{rank}")
+    dist.destroy_process_group()
+
+
+def test_every_handoff_leaves_within_one_stage_of_sink_or_consumer_ready(tmp_path):
+    """the regression the handshake bug was (every hand-off left at the END of the producer's chunk and the wavefront
+    ran chunk after chunk), stated on ChunkHandoff.stats over 3 x lanes chunks: a hand-off is issued within one stage time of the
+    later of {its sink, its consumer's announcement} -- at the sink when the consumer is idle, at the next stage-boundary poll when
+    the consumer was still inside its previous chunk -- and the wavefront's wall clock shows the overlap."""
+    out, stage_s, world = str(tmp_path / "six"), 0.3, 2
+    mp.spawn(_six_chunk_worker, args=(world, _free_port(), out, stage_s), nprocs=world, join=True)
+    rs = [torch.load(f"{out}.{r}") for r in range(world)]
+    stats, marks = {}, {}
+    for r in rs:
+        for c, st in r["stats"].items():
+            stats.setdefault(c, {}).update(st)          # producer side: t_sink, t_issued; consumer side: t_ready, t_recv_done
+        marks.update(r["marks"])
+    assert sorted(stats) == [1, 2, 3, 4, 5]
+    for c, st in sorted(stats.items()):
+        late = st["t_issued"] - max(st["t_sink"], st["t_ready"])
+        assert late < stage_s + 0.15, (c, late, st)
+        assert st["t_recv_done"] - st["t_issued"] < 0.5, (c, st)
+    # and the chunks overlap: 6 chunks of 4 stages on 2 lanes take about 3 chunk times + the first stagger, not 6
+    wall = max(m["t_end"] for m in marks.values()) - min(m["t_start"] for m in marks.values())
+    assert wall < 4.2 * 4 * stage_s, wall

@@ -82,3 +82,27 @@ def test_oracle_matches_reference_golden_trajectory():
             x = o.step(v, x)
             ref = fx[f"traj_{name}"][i]
             assert (x.float() - ref.float()).abs().max().item() <= (0.02 if dt == BF else 1e-4), (name, i)
+
+
+def test_gpu_scalar_semantics_vs_the_reference_itself():
+    """`sched.pt: traj_bf16_gpu_semantics` = the REAL FlowUniPCMultistepScheduler.step with its `sigmas` carrying
+    make_golden._GpuScalar (operands of scalar-first products swapped at dispatch: what PyTorch's GPU kernels compute; unedited
+    reference code).  (a) the oracle's `gpu_scalar_semantics=True` is that, bit for bit, over all 50 steps; (b) so is the HIP
+    kernel's arithmetic (emulate_kernel above, with fc == fu so that the CFG combine is the identity) -- HIP step arithmetic against
+    the reference with no oracle in between; (c) it is NOT the CPU-semantics trajectory."""
+    fx = torch.load(f"{GOLDEN}/sched.pt")
+    ref = fx["traj_bf16_gpu_semantics"]
+    assert ref.shape[0] == 50 and (ref.float() - fx["traj_bf16"].float()).abs().max().item() > 1e-2
+    x, target = philox_normal([1, 3, 4, 6, 8], 5, BF), philox_normal([1, 3, 4, 6, 8], 6, BF)
+    o = FlowUniPCRef(1000, 2, 1.0, gpu_scalar_semantics=True)
+    o.set_timesteps(50, shift=5.0)
+    s = FlowUniPCMultistepScheduler(1000, 2, 1.0)
+    s.set_timesteps(50, shift=5.0)
+    xo, xk = x.clone(), x.clone()
+    m0 = m1 = last = torch.zeros_like(x)
+    for i in range(50):
+        xo = o.step((xo - target) * (1.0 + 0.1 * torch.sin(xo.float() * 3 + i).to(BF)), xo)
+        assert torch.equal(xo, ref[i]), ("oracle", i)
+        v = (xk - target) * (1.0 + 0.1 * torch.sin(xk.float() * 3 + i).to(BF))
+        xk, m0, m1, last = emulate_kernel(s.step_scalars(5.0), v, v, xk, m0, m1, last)
+        assert torch.equal(xk, ref[i]), ("kernel arithmetic", i)

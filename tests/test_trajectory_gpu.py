@@ -114,14 +114,17 @@ def test_t2v_chunk_50_steps_vs_reference_algorithm_on_its_native_platform():
 
 def test_t2v_chunk_50_steps_vs_gpu_semantics_fixture():
     """HIP against the COMMITTED 408-forward fixture under the reference's native-platform scalar semantics
-    (tests/golden/chunk_t2v_tiny_50_gpu_semantics.pt, make_golden.py chunk50_gpu: the oracle -- pinned to the reference with the
-    switch off -- with nothing but the operand order of the UniPC scalar products changed).  That fixture sits 2.3e-2 from the
-    CPU-semantics one: the whole HIP-vs-CPU-reference distance of the first test is the platform's scalar rounding, not the
-    kernels.  Bound: 2 x the reference's own K/V-order noise over the same trajectory."""
+    (tests/golden/chunk_t2v_tiny_50_gpu_semantics.pt, make_golden.py chunk50_gpu).  Since round 5 the REAL reference produces it:
+    its model and its unedited FlowUniPCMultistepScheduler.step, with `scheduler.sigmas` carrying a tensor subclass that swaps the
+    operands of scalar-first products at dispatch (what PyTorch's GPU kernels compute; bit-identical to the oracle's switch on the
+    toy trajectory, tests/test_scheduler_host.py).  That fixture sits 2.3e-2 from the CPU-semantics one: the whole
+    HIP-vs-CPU-reference distance of the first test is the platform's scalar rounding, not the kernels.  Bound: 2 x the reference's
+    own K/V-order noise over the same trajectory -- now stated against a reference-produced file."""
     from tests.test_pipeline_gpu import _setup
     fx = torch.load(f"{GOLDEN}/chunk_t2v_tiny_50_gpu_semantics.pt")
     nf = torch.load(f"{GOLDEN}/chunk_t2v_tiny_50.pt")["noise_floor"]
     m = fx["meta"]
+    assert "REAL reference" in fx["produced_by"]
     lat, hand = _hip_50()
     e, eh = rel_l2(lat[..., ::2, ::2], fx["out_strided"]), rel_l2(hand[..., ::3, ::3], fx["handoff_strided"])
     print(f"408 forwards at 60x104: HIP vs the GPU-semantics fixture: latents {e:.3e} hand-off {eh:.3e} (bound {2 * nf['order_out']:.3e}; "
@@ -158,3 +161,29 @@ def test_chunk_50_steps_vs_oracle_small_geometry(mode):
     e, eh = rel_l2(lat, o_out), rel_l2(hand, o_hand)
     print(f"{mode} 50 steps at 16x24: rel_l2(HIP, oracle) latents {e:.3e} hand-off {eh:.3e} (bound {bound:.3e})")
     assert e <= bound and eh <= bound
+
+
+@pytest.mark.parametrize("steps,n_init", [(2, 1), (2, 2), (50, 1), (50, 2)])
+def test_i2v_chunk_vs_reference_fixture_directly(steps, n_init):
+    """The I2V stage plan (BASELINE configs[4]) at 60x104 against what the REAL reference computed (tests/golden/chunk_i2v_tiny*.pt,
+    make_golden.py chunk_i2v / chunk_i2v50: MMPL_i2v/pipeline/casual_fps_inference.py:253-435 driven through the reference model
+    and UniPC under GPU scalar semantics): a first chunk (initial_latent = the image latent) and a later chunk (two initial
+    latents, both refreshed), 2 and 50 UniPC steps per stage, final latents and the 3-frame hand-off -- no oracle in between.
+    Bounds as for T2V: 1.1e-2 after 2 steps per stage, 2 x the reference's K/V-order noise (1.3e-2) after 50."""
+    from mmpl_amd.synthetic import philox_normal
+    from tests.test_pipeline_gpu import _setup
+    fx = torch.load(f"{GOLDEN}/chunk_i2v_tiny{'_50' if steps == 50 else ''}.pt")
+    nf = torch.load(f"{GOLDEN}/chunk_t2v_tiny_50.pt")["noise_floor"]
+    m, e = fx["meta"], fx[f"init{n_init}_gpu"]
+    assert m["steps"] == steps and "REAL reference" in fx["produced_by"]
+    pipe, *_ = _setup("i2v", steps=steps, lat=(H, Wd))
+    noise = philox_normal([1, 21, 16, H, Wd], m["noise_seed"])
+    initial = philox_normal([1, 2, 16, H, Wd], m["initial_seed"])[:, :n_init].contiguous()
+    lat, hand = _hip_chunk(pipe, noise, None, initial)
+    e_out, e_hand = rel_l2(lat[..., ::4, ::2], e["out_strided"]), rel_l2(hand[..., ::3, ::3], e["handoff_strided"])
+    e_cpu = rel_l2(lat[..., ::4, ::2], fx[f"init{n_init}_cpu"]["out_strided"])
+    bound = 1.1e-2 if steps == 2 else 2 * nf["order_out"]
+    print(f"i2v {steps} steps, {n_init} initial frame(s) at 60x104: HIP vs the reference (GPU scalar semantics) out {e_out:.3e} hand-off {e_hand:.3e} "
+          f"(bound {bound:.2e}; the oracle measured {e['oracle_out']:.3e}); vs the reference's CPU-semantics run {e_cpu:.3e}")
+    assert torch.equal(lat[:, :n_init], initial) and hand.shape == (1, 3, 16, H, Wd)
+    assert e_out <= bound and e_hand <= bound

@@ -112,3 +112,80 @@ def test_cli_two_ranks_gloo_one_gpu(tmp_path):
     v = torch.load(out / "0-0.pt")
     assert v.shape == (81 + 76 + 76, 128, 192, 3) and v.dtype == torch.uint8
     assert v.float().std() > 1.0
+
+
+def _six_worker(rank, port, out_path, n_chunks, steps):
+    import time
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2, timeout=datetime.timedelta(seconds=600))
+    try:
+        from mmpl_amd.handoff import ChunkHandoff, handoff_to_initial_latent, run_chunk_wavefront
+        from tests.test_pipeline_gpu import LAT, _setup
+        pipe, *_ = _setup("t2v", steps=steps, with_vae=True)
+        ho = ChunkHandoff((1, 8, 16, *LAT), "cuda:0")
+        marks = {}
+
+        def make_chunk(c, initial, sink):
+            torch.manual_seed(4000 + c)
+            m = marks.setdefault(c, {"bounds": []})
+
+            def poll():                                        # the pipeline calls this at every stage boundary after the anchor stage
+                m["bounds"].append(time.time())
+                return ho.poll()
+
+            def tee(t):
+                torch.cuda.synchronize()
+                m["t_anchor"] = time.time()
+                sink(t)
+            pipe.handoff_sink, pipe.handoff_poll = tee, poll
+            m["t_start"] = time.time()
+            _, lat = pipe.inference(_noise(c).cuda(), ["a cat"], initial_latent=initial, return_latents=True, decode=False)
+            torch.cuda.synchronize()
+            m["t_end"] = time.time()
+            return lat
+
+        # one untimed chunk: graph captures / allocations out of the way, so that the stage times below are steady
+        pipe.handoff_sink = lambda t: None
+        pipe.inference(_noise(99).cuda(), ["warm-up"], return_latents=True, decode=False)
+        torch.cuda.synchronize()
+        dist.barrier()
+        run_chunk_wavefront(make_chunk, n_chunks, ho, lambda t: handoff_to_initial_latent(pipe.vae, t.cuda()), gather=False)
+        torch.cuda.synchronize()
+        torch.save({"stats": ho.stats, "marks": marks}, f"{out_path}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_wavefront_three_chunks_per_lane_handoffs_leave_within_one_stage(tmp_path):
+    """n_chunks = 3 x lanes through the REAL pipeline on two ranks (gloo, one GPU): from ChunkHandoff.stats, every
+    hand-off is issued within one stage time of the later of {its sink, its consumer's "ready"} -- at the sink when the consumer
+    idles, at the producer's next stage-boundary poll when the consumer was still inside its previous chunk (wrap-around: chunks
+    2 .. 5 run on a lane that is busy when their anchors are ready).  The handshake bug of round 4 (every hand-off left at the END
+    of the producer's chunk; the wavefront ran chunk after chunk) fails this: it was late by the two in-fill stages."""
+    import torch.multiprocessing as mp
+    n_chunks, steps = 6, 6
+    out = str(tmp_path / "six")
+    mp.spawn(_six_worker, args=(_free_port(), out, n_chunks, steps), nprocs=2, join=True)
+    rs = [torch.load(f"{out}.{r}") for r in range(2)]
+    stats, marks = {}, {}
+    for r in rs:
+        for c, st in r["stats"].items():
+            stats.setdefault(c, {}).update(st)
+        marks.update(r["marks"])
+    assert sorted(stats) == [1, 2, 3, 4, 5] and sorted(marks) == list(range(n_chunks))
+    # stage times of the producer of chunk c's hand-off (chunk c - 1): anchor stage end -> in-fill boundary -> chunk end
+    worst = 0.0
+    for c in range(1, n_chunks):
+        m, st = marks[c - 1], stats[c]
+        edges = [m["t_anchor"]] + m["bounds"] + [m["t_end"]]
+        stage_s = max(b - a for a, b in zip(edges[:-1], edges[1:]))
+        late = st["t_issued"] - max(st["t_sink"], st["t_ready"])
+        worst = max(worst, late / stage_s)
+        print(f"hand-off for chunk {c}: issued {late * 1e3:7.1f} ms after max(sink, ready); producer's longest stage after the sink {stage_s * 1e3:7.1f} ms; "
+              f"consumer ready {(st['t_ready'] - st['t_sink']) * 1e3:+8.1f} ms relative to the sink")
+        assert late < stage_s + 0.25, (c, late, stage_s, st)
+        assert st["t_issued"] < m["t_end"] + 0.25 or st["t_ready"] > m["t_end"], (c, st, m)     # not parked until the end of the producer's chunk
+    # the wrap-around case really occurred: some consumer announced itself AFTER its producer's sink (so the send was deferred)
+    assert any(stats[c]["t_ready"] > stats[c]["t_sink"] for c in range(2, n_chunks)), stats

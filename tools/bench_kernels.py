@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmarks of the two MFMA kernels on the 14B/720p shapes (dev tool).
-    python tools/bench_kernels.py attn|gemm|all [--iters N]"""
+    python tools/bench_kernels.py attn|gemm|all|gemmref|attnref [--iters N]"""
 import ctypes as C
 import math
 import os
@@ -48,6 +48,48 @@ def bench_attn(iters):
         ms = timeit(fn, iters)
         fl = 4.0 * Lq * npg_ * pr * d
         print(f"attn {name}: Lq={Lq} Lkv={npg_ * pr}  {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s", flush=True)
+
+
+def bench_attn_ref(iters):
+    """yardstick only (never on the product path): PyTorch-ROCm's scaled_dot_product_attention (its flash / memory-efficient backends:
+    AOTriton / CK as the wheel was built) on the self-attention shapes of the 14B / 720p stages, K / V gathered CONTIGUOUS (what the
+    reference materialises per layer before calling flash-attn, causal_fps_model.py:219-227) -- the gather itself is not timed.
+    Next to it: mmpl_attn_fwd on the same q / k / v values (paged, in place)."""
+    import torch.nn.functional as F
+    from torch.nn.attention import SDPBackend, sdpa_kernel
+    H, S, d = 40, 3600, 5120
+    for name, nq, nkv in (("s0", 2, 2), ("s1", 7, 9), ("s2", 6, 13), ("s3", 6, 21)):
+        Lq, Lkv = nq * S, nkv * S
+        q = torch.randn(Lq, d, device=dev).to(BF)
+        k = torch.randn(Lkv, d, device=dev).to(BF)
+        v = torch.randn(Lkv, d, device=dev).to(BF)
+        fl = 4.0 * Lq * Lkv * d
+        o = torch.empty(Lq, d, device=dev, dtype=BF)
+        kp = (C.c_void_p * nkv)(*[k[i * S:].data_ptr() for i in range(nkv)])
+        vp = (C.c_void_p * nkv)(*[v[i * S:].data_ptr() for i in range(nkv)])
+        ws = torch.empty(lib.mmpl_attn_workspace_bytes(), dtype=torch.uint8, device=dev)
+        fn = lambda: _lib.check(lib.mmpl_attn_fwd_variant(_lib.ptr(q), d, _lib.ptr(o), d, kp, vp, d, d, nkv, S, Lq, H, 1 / math.sqrt(128),
+                                                          _lib.ptr(ws), ws.numel(), 3, 0, _lib.stream_ptr()))
+        ms = min(timeit(fn, iters), timeit(fn, iters))
+        print(f"attnref {name}: Lq={Lq} Lkv={Lkv}  mmpl attn_w64 (paged, raw q) {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s", flush=True)
+        # [B=1, H, L, 128] views of the token-major tensors (what flash-attn style kernels take) and head-major contiguous copies
+        for layout in ("token-major views", "head-major contiguous"):
+            q4, k4, v4 = (t.view(1, -1, H, 128).transpose(1, 2) for t in (q, k, v))
+            if layout.startswith("head"):
+                q4, k4, v4 = q4.contiguous(), k4.contiguous(), v4.contiguous()
+            for be in (SDPBackend.FLASH_ATTENTION, SDPBackend.EFFICIENT_ATTENTION):
+                try:
+                    with sdpa_kernel([be]):
+                        f2 = lambda: F.scaled_dot_product_attention(q4, k4, v4)
+                        ref = f2()
+                        ms2 = min(timeit(f2, iters), timeit(f2, iters))
+                    err = ((ref.transpose(1, 2).reshape(Lq, d).float() - o.float()).norm() / o.float().norm()).item()
+                    print(f"attnref {name}: torch SDPA {be.name:22s} {layout:22s} {ms2:8.3f} ms  {fl / ms2 / 1e9:8.1f} TFLOP/s   (rel-L2 vs mmpl {err:.2e})", flush=True)
+                    del ref
+                except Exception as e:
+                    print(f"attnref {name}: torch SDPA {be.name} {layout}: unavailable ({str(e).splitlines()[0][:120]})", flush=True)
+            del q4, k4, v4
+        del q, k, v, o
 
 
 def bench_gemm(iters):
@@ -131,3 +173,5 @@ if __name__ == "__main__":
         bench_gemm(iters)
     if what == "gemmref":
         bench_gemm_ref(iters)
+    if what == "attnref":
+        bench_attn_ref(iters)

@@ -37,7 +37,6 @@ B_FIXED = {g: [] for g in range(32)}
 K_DMA = [int(x) for x in os.environ.get("W64_KDMA", "4,8,12,16").split(",")]
 V_DMA = [int(x) for x in os.environ.get("W64_VDMA", "20,24,28,36").split(",")]
 W_DMA = float(os.environ.get("W64_WDMA", BUDGET - 1))
-PVSPLIT = bool(int(os.environ.get("W64_PVSPLIT", "0")))     # dev (timing mock, with -DW64_ABL=256): see mfma_pv_h in attn_w64.hip
 
 
 def _fixed(g):
@@ -167,18 +166,13 @@ def emit():
                 lines.append("  if constexpr (QK && !PV) k.mfma_write_pad();")
             sm = interleave(placed[base + g])
             fx = list(fixed[g])
-            if PVSPLIT and g >= 16:
-                lines.pop()                                   # dev mock: two half-size MFMAs, the gap's fillers split around the second
-                lines.append(f"  if constexpr (PV) k.template mfma_pv_h<{x}, {g - 16}, 0>();")
             body = []
             # fixed fillers go after the first softmax op (so that an LDS / DMA op does not sit right behind the MFMA issue)
             if sm:
                 body.append(sm.pop(0))
             body += [("F",) + f for f in fx]
             body += sm
-            for bi, o in enumerate(body):
-                if PVSPLIT and g >= 16 and bi == (len(body) + 1) // 2:
-                    lines.append(f"  if constexpr (PV) k.template mfma_pv_h<{x}, {g - 16}, 1>();")
+            for o in body:
                 if o[0] == "F":
                     _, fl, stmt, _ = o
                     cond = {"QK": "QK", "PV": "PV", "!QK": "!QK", "S0": "S0", "S1": "S1"}[fl]
@@ -186,8 +180,6 @@ def emit():
                 else:
                     xs, op, q = o
                     lines.append(f"  if constexpr (S{xs}) k.template sm_{op}<MODE, {xs}, {q}>();")
-            if PVSPLIT and g >= 16 and len(body) <= (len(body) + 1) // 2:
-                lines.append(f"  if constexpr (PV) k.template mfma_pv_h<{x}, {g - 16}, 1>();")
             for xs in (1, 0):
                 if last[xs] == base + g:
                     lines.append(f"  if constexpr (S{xs}) k.template finish<MODE, {xs}>();")

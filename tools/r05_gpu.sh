@@ -1,0 +1,62 @@
+#!/bin/bash
+# Round 5: ONE script for every gpurun call -- named steps, each writing gpurun_out/<tag>/<step>.log (copy what is judged into profiles/).
+#   usage: bash tools/r05_gpu.sh <tag> <step> [<step> ...]
+# Steps that rebuild the library with experiment defines (MMPL_EXTRA_HIPCC_FLAGS) restore the plain build when they are done.
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+tag=$1; shift; out=gpurun_out/$tag; mkdir -p $out
+BIG="qkv:25200:15360:5120:0,o:25200:5120:5120:3,ffn0:25200:13824:5120:1,ffn2:25200:5120:13824:3"
+S13="qkv_s1:10920:4608:1536:0,o_s1:10920:1536:1536:3,ffn0_s1:10920:8960:1536:1,ffn2_s1:10920:1536:8960:3,qkv_s2:9360:4608:1536:0,o_s2:9360:1536:1536:3,ffn0_s2:9360:8960:1536:1,ffn2_s2:9360:1536:8960:3,qkv_s0:3120:4608:1536:0,o_s0:3120:1536:1536:3"
+build() { MMPL_EXTRA_HIPCC_FLAGS="$1" python -m mmpl_amd.build > $out/build.log 2>&1 || { echo "BUILD FAILED ($1)"; tail -5 $out/build.log; }; }
+line() {   # one bench line -> "<label> step .. stages .. attn .. gemm .. redo .."
+  python3 -c "
+import json,sys
+r=json.loads(open('$1').read().strip().splitlines()[-1]); rf=r.get('roofline',{})
+print('$2', 'step', round(r['sec_per_denoise_step'],4), [round(x,4) for x in r['sec_per_denoise_step_by_stage']], 'attn', round(rf.get('achieved',0),1), 'frac', round(rf.get('frac',0),4),
+      'of_sustained', round(rf.get('frac_of_sustained',0),4), 'probe', {k[-12:]:round(v) for k,v in (rf.get('sustained_probe_tflops') or {}).items()}, 'gemm', r.get('gemm_tflops'), 'redo', r.get('attn_blocks_redone_fraction'))"
+}
+for step in "$@"; do
+  echo "=== $step"
+  case $step in
+    suite)
+      python -m pytest tests -m gpu -q -x --deselect tests/test_rccl_loopback_gpu.py > $out/gputests.log 2>&1; echo "pytest rc=$?" >> $out/gputests.log; tail -4 $out/gputests.log
+      python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; tail -1 $out/smoke.log ;;
+    suite_noexit)
+      python -m pytest tests -m gpu -q --deselect tests/test_rccl_loopback_gpu.py > $out/gputests.log 2>&1; echo "pytest rc=$?" >> $out/gputests.log; tail -8 $out/gputests.log
+      python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; tail -1 $out/smoke.log ;;
+    rccl)        # last in a call: a transport that hangs must not take the other results with it
+      timeout 400 python -m pytest tests/test_rccl_loopback_gpu.py -m gpu -q -s > $out/rccl_loopback.log 2>&1; echo "rc=$?" >> $out/rccl_loopback.log; tail -15 $out/rccl_loopback.log ;;
+    newtests)
+      python -m pytest tests/test_dit_forward_gpu.py tests/test_bench_multirank_gpu.py tests/test_wavefront_gpu.py tests/test_trajectory_gpu.py -m gpu -q -s > $out/newtests.log 2>&1; echo "rc=$?" >> $out/newtests.log
+      grep -E "hand-off for chunk|408 forwards|24 forwards|50 steps|i2v|passed|failed|rc=" $out/newtests.log | tail -40 ;;
+    bench)
+      python bench.py > $out/bench_14B_720p.json 2> $out/bench.err; line $out/bench_14B_720p.json default ;;
+    profall)
+      python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae --profile-all > $out/bench_14B_720p_profile_all.json 2>> $out/bench.err; line $out/bench_14B_720p_profile_all.json profile-all ;;
+    bench13)
+      python bench.py --model 1.3B --res 480p --no-cpu-baseline --profile-all > $out/bench_1p3B_480p.json 2>> $out/bench.err; line $out/bench_1p3B_480p.json 1.3B/480p ;;
+    attnref)
+      timeout 900 python tools/bench_kernels.py attnref --iters 3 > $out/attn_sdpa_yardstick.log 2>&1; cat $out/attn_sdpa_yardstick.log ;;
+    gemm13)      # the 1.3B / 480p block shapes: default launcher, every GEMM on the small tiles, the vendor library
+      for e in "A=0" "MMPL_GEMM_V2=1" "MMPL_GEMM_V1=1" "A=0"; do echo "== $e" >> $out/gemm13.log; env $e BENCH_SHAPES=$S13 timeout 300 python tools/bench_kernels.py gemm --iters 20 2>&1 | grep "^gemm" >> $out/gemm13.log; done
+      BENCH_SHAPES=$(echo $S13 | sed 's/:[0-9]*,/,/g; s/:[0-9]*$//') timeout 300 python tools/bench_kernels.py gemmref --iters 20 2>&1 | grep "^vendor" >> $out/gemm13.log; cat $out/gemm13.log ;;
+    gemmM2)      # mock of cond + uncond batched along M: the same four block GEMMs at M = 25200 and M = 50400
+      for m in 25200 50400 25200 50400; do echo "== M=$m" >> $out/gemm_m2.log; BENCH_SHAPES=$(echo $BIG | sed "s/25200/$m/g") timeout 300 python tools/bench_kernels.py gemm --iters 5 2>&1 | grep "^gemm" >> $out/gemm_m2.log; done; cat $out/gemm_m2.log ;;
+    polsweep)    # cache policy of the operand streams (LDS-DMA loads): A / W x {nt, sc1}
+      for f in "" "-DGEMM_POLICY_A=1" "-DGEMM_POLICY_W=1" "-DGEMM_POLICY_A=1 -DGEMM_POLICY_W=1" "-DGEMM_POLICY_A=2" "-DGEMM_POLICY_W=2" ""; do
+        build "$f"; echo "== flags [$f]" >> $out/gemm_policy.log
+        BENCH_SHAPES=$BIG timeout 300 python tools/bench_kernels.py gemm --iters 5 2>&1 | grep "^gemm" >> $out/gemm_policy.log
+      done; build ""; cat $out/gemm_policy.log ;;
+    vb128)       # attention: V fragments by one ds_read_b128 (timing mock of a pre-transposed V tile), in situ, alternating with the shipping build
+      for f in "" "-DW64_ABL=256" "" "-DW64_ABL=256"; do
+        build "$f"; python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae > $out/vb128_tmp.json 2>> $out/bench.err; line $out/vb128_tmp.json "[$f]" >> $out/attn_vb128_mock.log
+      done; build ""; cat $out/attn_vb128_mock.log ;;
+    refoff)      # FAST-pass window: reference offset / lower bound rebalanced, heavy tail x8 and x5 and the default weights
+      for f in "" "-DW64_REF_OFFSET=96 -DW64_LMIN_EXP=124" "-DW64_REF_OFFSET=80 -DW64_LMIN_EXP=124"; do
+        build "$f"
+        for g in 8 5; do python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae --heavy-tail --heavy-tail-gain $g > $out/refoff_tmp.json 2>> $out/bench.err; line $out/refoff_tmp.json "[$f] heavy-tail x$g" >> $out/attn_fast_window.log; done
+        python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae --attn-stats > $out/refoff_tmp.json 2>> $out/bench.err; line $out/refoff_tmp.json "[$f] default weights" >> $out/attn_fast_window.log
+      done; build ""; cat $out/attn_fast_window.log ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
+ls -la $out
