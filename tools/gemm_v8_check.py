@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""dev: sha256 of the large-GEMM outputs per (shape, epilogue, entry point).  Run once with MMPL_GEMM_V8=0 and once with =1 and diff the
-two listings: gemm_bf16_v8_kernel issues the same MFMAs in the same per-accumulator order as v6, so every line must agree."""
+"""dev: sha256 of the large-GEMM outputs per (shape, epilogue, entry point).  Run once with MMPL_GEMM_V8=0 and once with =1 (or
+MMPL_GEMM_V9=0 / 1) and diff the two listings: gemm_bf16_v8_kernel and gemm_bf16_v9_kernel issue the same MFMAs in the same
+per-accumulator order as v6, so every line must agree (except the `scratch` column of a K >= 4096 shape under MMPL_GEMM_V9=1: v9
+has no split-K tail, whose partial sums are added in another -- fixed -- order)."""
 import hashlib
 import math
 import os
@@ -15,7 +17,7 @@ lib = _lib.load()
 dev = "cuda:0"
 BF = torch.bfloat16
 shapes = [(25200, 15360, 5120, 0), (25200, 5120, 5120, 3), (21600, 13824, 5120, 1), (25200, 5120, 13824, 3), (7200, 5120, 5120, 1),
-          (10920, 1536, 1536, 3), (10920, 1536, 8960, 3), (3120, 4608, 1536, 0), (4096, 5120, 5120, 4), (1030, 264, 192, 2), (2000, 520, 128, 0)]
+          (10920, 1536, 1536, 3), (10920, 1536, 8960, 3), (3120, 4608, 1536, 0), (9360, 1536, 1536, 4), (3120, 1536, 1536, 3), (10920, 4608, 1536, 0), (9360, 8960, 1536, 1), (1560, 1536, 1536, 2), (4096, 5120, 5120, 4), (1030, 264, 192, 2), (2000, 520, 128, 0)]
 for M, N, K, epi in shapes:
     torch.manual_seed(M + N + K + epi)
     A = torch.randn(M, K, device=dev).to(BF)

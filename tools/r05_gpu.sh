@@ -56,6 +56,28 @@ for step in "$@"; do
         for g in 8 5; do python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae --heavy-tail --heavy-tail-gain $g > $out/refoff_tmp.json 2>> $out/bench.err; line $out/refoff_tmp.json "[$f] heavy-tail x$g" >> $out/attn_fast_window.log; done
         python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae --attn-stats > $out/refoff_tmp.json 2>> $out/bench.err; line $out/refoff_tmp.json "[$f] default weights" >> $out/attn_fast_window.log
       done; build ""; cat $out/attn_fast_window.log ;;
+    v9)          # gemm_bf16_v9_kernel (256 x 128 tiles, two blocks per CU): bit-identity with v6 / v8, the GEMM tests on it, timing on the 1.3B shapes
+      MMPL_GEMM_V9=0 timeout 600 python tools/gemm_v8_check.py > $out/gemm_v9off_sha.log 2>&1
+      MMPL_GEMM_V9=1 timeout 600 python tools/gemm_v8_check.py > $out/gemm_v9on_sha.log 2>&1
+      diff $out/gemm_v9off_sha.log $out/gemm_v9on_sha.log > $out/gemm_v9_vs_v6.diff && echo "v9 == v6 / v8 bit for bit on every line" | tee -a $out/gemm_v9_vs_v6.diff; head -20 $out/gemm_v9_vs_v6.diff
+      MMPL_GEMM_V9=1 python -m pytest tests/test_kernels_gpu.py -m gpu -q -k "gemm" 2>&1 | tail -3 > $out/test_gemm_v9.log; cat $out/test_gemm_v9.log
+      for e in "MMPL_GEMM_V9=0" "MMPL_GEMM_V9=1 MMPL_GEMM_V9_STAGGER=0" "MMPL_GEMM_V9=1 MMPL_GEMM_V9_STAGGER=2" "MMPL_GEMM_V9=1 MMPL_GEMM_V9_STAGGER=4" "MMPL_GEMM_V9=1 MMPL_GEMM_V9_STAGGER=8" "A=0" "MMPL_GEMM_V9=0"; do
+        echo "== $e" >> $out/gemm_v9_timing.log; env $e BENCH_SHAPES=$S13 timeout 300 python tools/bench_kernels.py gemm --iters 20 2>&1 | grep "^gemm" >> $out/gemm_v9_timing.log
+      done
+      for e in "MMPL_GEMM_V9=0" "MMPL_GEMM_V9=1" "MMPL_GEMM_V9=0" "MMPL_GEMM_V9=1"; do      # ... and, for the record, on the 14B / 720p block shapes
+        echo "== $e (14B / 720p shapes)" >> $out/gemm_v9_timing.log; env $e BENCH_SHAPES=$BIG timeout 300 python tools/bench_kernels.py gemm --iters 5 2>&1 | grep "^gemm" >> $out/gemm_v9_timing.log
+      done; cat $out/gemm_v9_timing.log ;;
+    bench13ab)   # 1.3B / 480p in situ: v9 off / default / off / default
+      for e in "MMPL_GEMM_V9=0" "A=0" "MMPL_GEMM_V9=0" "A=0"; do env $e python bench.py --model 1.3B --res 480p --no-cpu-baseline --no-vae --profile-all > $out/b13_tmp.json 2>> $out/bench.err; line $out/b13_tmp.json "[$e]" >> $out/bench_1p3B_v9_ab.log; done; cat $out/bench_1p3B_v9_ab.log ;;
+    refoff2)     # the same with ONE reference per query row (round 5 kernel): offsets 64 (shipping window) / 88 / 100
+      for f in "" "-DW64_REF_OFFSET=88 -DW64_LMIN_EXP=124" "-DW64_REF_OFFSET=100 -DW64_LMIN_EXP=124"; do
+        build "$f"
+        for g in 8 5; do python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae --heavy-tail --heavy-tail-gain $g > $out/refoff_tmp.json 2>> $out/bench.err; line $out/refoff_tmp.json "per-row reference [$f] heavy-tail x$g" >> $out/attn_fast_window_per_row.log; done
+        python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae --attn-stats > $out/refoff_tmp.json 2>> $out/bench.err; line $out/refoff_tmp.json "per-row reference [$f] default weights" >> $out/attn_fast_window_per_row.log
+      done; build ""; cat $out/attn_fast_window_per_row.log ;;
+    kerneltests)
+      python -m pytest tests/test_kernels_gpu.py tests/test_wavefront_gpu.py tests/test_dit_forward_gpu.py tests/test_fullsize_gpu.py -m gpu -q -s > $out/kerneltests.log 2>&1; echo "rc=$?" >> $out/kerneltests.log
+      grep -E "hand-off for chunk|deferred at|passed|failed|rc=|Error" $out/kerneltests.log | tail -20 ;;
     *) echo "unknown step $step" ;;
   esac
 done
