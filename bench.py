@@ -84,6 +84,9 @@ def parse():
                          "(the reference's device_cond/device_uncond seam) instead of N chunk lanes; default from 4 ranks on")
     ap.add_argument("--no-cfg-split", action="store_true", help="N chunk lanes whatever N is")
     ap.add_argument("--eager", action="store_true", help="time plain launches instead of one hipGraph replay per step")
+    ap.add_argument("--concurrent-cfg", action="store_true",
+                    help="the cond and the uncond forward of a step as two PARALLEL branches of the step graph (a second stream, a private "
+                         "workspace): the tail of one branch's kernels (partial last rounds, split tails, launch gaps) is filled by the other's")
     ap.add_argument("--wavefront-chunks", type=int, default=0,
                     help="C > 0: instead of K rotating steps, run ONE video of C chunks through the real pipeline and the real dependency chain "
                          "(chunk c on lane c %% lanes, RCCL anchor hand-off after the anchor stage, VAE consumer transform) and report the MEASURED "
@@ -576,10 +579,24 @@ def main():
             st["t"].fill_(float(sched.timesteps[0]))
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
+            if args.concurrent_cfg and "ws2" not in st:
+                st["ws2"] = torch.empty(eng.workspace(len(st["frames"])).numel(), dtype=torch.uint8, device=dev)
+                st["side"] = torch.cuda.Stream(device=dev)
             with torch.cuda.graph(g):
-                for which, out in ((0, st["fc"]), (1, st["fu"])):
-                    kc, vc, ck, cv, crows = caches[which]
-                    eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out, cross_rows=crows)
+                if args.concurrent_cfg:
+                    x_in = xin(st)
+                    main = torch.cuda.current_stream()
+                    st["side"].wait_stream(main)                      # fork: the uncond branch on a second captured stream
+                    kc, vc, ck, cv, crows = caches[0]
+                    eng.forward(x_in, st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=st["fc"], cross_rows=crows)
+                    with torch.cuda.stream(st["side"]):
+                        kc, vc, ck, cv, crows = caches[1]
+                        eng.forward(x_in, st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=st["fu"], cross_rows=crows, workspace=st["ws2"])
+                    main.wait_stream(st["side"])                      # join
+                else:
+                    for which, out in ((0, st["fc"]), (1, st["fu"])):
+                        kc, vc, ck, cv, crows = caches[which]
+                        eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out, cross_rows=crows)
                 sched.step_cfg_table(st["fc"], st["fu"], st["lat"], st["t"])
             st["graph"], st["replays"] = g, 0
     if pair is not None and not args.eager:
@@ -701,7 +718,8 @@ def main():
                                    f"rotating the four {args.mode.upper()} denoise stages {stage_shapes} (query, attended frames); one "
                                    f"21-latent-frame chunk per GPU = 204 step-equivalents",
                        "frame_seqlen": S, "latent_hw": [lat_h, lat_w], "sampling_steps": 50, "guidance_scale": 5.0,
-                       "timed_path": ("one hipGraph replay per denoise step (2 DiT forwards + fused CFG/UniPC, device-resident step tables)"
+                       "timed_path": ("one hipGraph replay per denoise step (2 DiT forwards" + (" as two parallel branches" if args.concurrent_cfg else "") +
+                                      " + fused CFG/UniPC, device-resident step tables)"
                                       if use_graph else ("one hipGraph replay per forward + host-issued flow exchange + fused CFG/UniPC launch"
                                                          if pair is not None and not args.eager else "eager launches")),
                        "model_type": "i2v (in_dim 36 + CLIP image stream)" if args.i2v_model else "t2v",

@@ -25,8 +25,7 @@
 // tile's first MFMA (the register tile that also carries the ragged-tile mask holds -m_ref instead of 0), so S arrives already
 // shifted: one v_exp, one add and half a cvt_pk per score, and NOTHING per tile that could branch.  m_ref = 64 + the largest score of
 // the block's first FOUR KV tiles (the ones the prologue has in the ring before the pipeline starts: 128 extra MFMAs per 256-row
-// block), ONE PER QUERY ROW (round 5: the C-operand tile exists once per query block; round 4 shared one value between a lane's two
-// rows, which cost the row with the smaller maximum that much of the window on the low side).
+// block; a lane's two query rows share one value).
 // Every p is >= 0, so the row sums only grow: one look at them after the last tile tells whether any exponential overflowed
 // (2^-100 <= l <= 2^100 is required, NaN fails) -- i.e. whether some later score beat the first tile's maximum by more than ~150
 // (log2 units; ~100 nats).  Round 3 used m_ref = 0, which holds for unit-gain synthetic weights only: with QK-norm gains x8 91 % of
@@ -54,7 +53,7 @@ constexpr int QB = 256, KVB = 64, TILE = KVB * 256, RING = 4;         // K ring 
 constexpr int W64_SMEM = 2 * RING * TILE + 64;     // + the block's redo flag
 constexpr float BOUND_GEN = 1073741824.f;                              // 2^30: a GENERAL tile's partial row sums
 #ifndef W64_LMIN_EXP
-#define W64_LMIN_EXP 100
+#define W64_LMIN_EXP 124
 #endif
 #ifndef W64_LMAX_EXP
 #define W64_LMAX_EXP 100
@@ -62,7 +61,7 @@ constexpr float BOUND_GEN = 1073741824.f;                              // 2^30: 
 constexpr float pow2f(int e) { return e == 0 ? 1.f : (e > 0 ? 2.f * pow2f(e - 1) : 0.5f * pow2f(e + 1)); }
 constexpr float FAST_L_MIN = pow2f(-W64_LMIN_EXP), FAST_L_MAX = pow2f(W64_LMAX_EXP);   // 2^-100, 2^100: a FAST pass's final row sums
 #ifndef W64_REF_OFFSET
-#define W64_REF_OFFSET 64
+#define W64_REF_OFFSET 80
 #endif
 constexpr float FAST_REF_OFFSET = W64_REF_OFFSET;   // FAST pass: m_ref = (largest score of the block's first FAST_REF_TILES KV tiles) + this
 #ifndef W64_REF_TILES
@@ -88,11 +87,11 @@ constexpr int AO = 0, AQ = 128, AV = 192;      // accumulator-file map
 struct Ctx {
   // ---- vector state
   f32x16 S[2][2];        // [query block][kv half]
-  f32x16 M[2][2];        // [query block][kv half] C operand of a score tile's first MFMA: mbase[X], or -inf on the rows past a page's end
+  f32x16 M[2];           // [kv half] C operand of a score tile's first MFMA: 0, or -inf on the rows past a page's end
   u32x4 P[2][4];         // [query block][16-row kv step]: 8 bf16 = B operand of O^T += V^T.P^T
   bf16x8 kf[16];         // K fragments of one tile: i = 2*chunk + half
   float l[2], mref[2];   // running row sum (this lane's 32 kv columns of every tile) and reference (log2 units)
-  float mbase[2];        // what an unmasked entry of the C-operand tile M[X] holds: -m_ref[X] in a FAST pass, 0 in a GENERAL one
+  float mbase;           // what an unmasked entry of the C-operand tile M holds: -m_ref in a FAST pass, 0 in a GENERAL one
   float la[2], lb[2];    // the tile's partial sums (even / odd register of each pair)
   float t[2][2][2];      // exp results in flight: [stream][pair parity][element]
   uint32_t dko[4], dvo[4];   // per-piece LDS-DMA source offsets within a tile (constant)
@@ -117,7 +116,7 @@ struct Ctx {
   template <int X, int G> MMPL_DEV void mfma_qk() {      // S_X[h] (+)= K frag G . Q_X[chunk]
     constexpr int c = G >> 1, h = G & 1, qa = AQ + 32 * X + 4 * c;
     if constexpr (c == 0)
-      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %4" : "=&v"(S[X][h]) : "v"(kf[G]), "i"(qa), "i"(qa + 3), "v"(M[X][h]));
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %4" : "=&v"(S[X][h]) : "v"(kf[G]), "i"(qa), "i"(qa + 3), "v"(M[h]));
     else
       asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(S[X][h]) : "v"(kf[G]), "i"(qa), "i"(qa + 3));
   }
@@ -230,13 +229,12 @@ struct Ctx {
     // register r of half h holds kv row 32 h + 8 (r >> 2) + (r & 3) + 4 hi: one compare of 4 hi against a scalar per register
     // (written as asm so that the 32 compares do not all stay live in SGPR pairs at once)
     const int hi4 = 4 * hi;
-    const float ninf = -INFINITY, zero0 = mbase[0], zero1 = mbase[1];
+    const float ninf = -INFINITY, zero = mbase;
     Ctx* self = this;
-    sfor<32>([self, hi4, ninf, zero0, zero1, valid](auto ii) {
+    sfor<32>([self, hi4, ninf, zero, valid](auto ii) {
       constexpr int i = decltype(ii)::value, h = i >> 4, r = i & 15;
       const int thr = valid - (32 * h + 8 * (r >> 2) + (r & 3));          // masked iff 4 hi >= thr
-      asm volatile("v_cmp_le_i32 vcc, %3, %2\n\tv_cndmask_b32 %0, %5, %4, vcc\n\tv_cndmask_b32 %1, %6, %4, vcc"
-                   : "=&v"(self->M[0][h][r]), "=v"(self->M[1][h][r]) : "v"(hi4), "s"(thr), "v"(ninf), "v"(zero0), "v"(zero1) : "vcc");
+      asm volatile("v_cmp_le_i32 vcc, %2, %1\n\tv_cndmask_b32 %0, %4, %3, vcc" : "=v"(self->M[h][r]) : "v"(hi4), "s"(thr), "v"(ninf), "v"(zero) : "vcc");
     });
     masked = 1;
   }
@@ -244,7 +242,7 @@ struct Ctx {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { M[0][h][r] = mbase[0]; M[1][h][r] = mbase[1]; }
+      for (int r = 0; r < 16; ++r) M[h][r] = mbase;
     masked = 0;
   }
   MMPL_DEV int plan(int j) {
@@ -345,10 +343,10 @@ struct Ctx {
     asm volatile("s_nop 1" ::: "memory");             // VALU-written P -> MFMA operand
     return lt;
   }
-  template <int X> MMPL_DEV float score_max() {          // largest of this lane's 32 scores of query block X (both kv halves)
+  MMPL_DEV float score_max() {                           // largest of this lane's 64 scores (both query blocks, both kv halves)
     float mx = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(S[X][0][r], S[X][1][r]));
+    for (int r = 0; r < 16; ++r) mx = fmaxf(fmaxf(mx, fmaxf(S[0][0][r], S[0][1][r])), fmaxf(S[1][0][r], S[1][1][r]));
     return mx;
   }
   template <int MODE, int X> MMPL_DEV void finish() {
@@ -369,7 +367,7 @@ template <int MODE> MMPL_DEV void w64_pass(Ctx& k) {
   k.l[0] = k.l[1] = 0.f;
   k.la[0] = k.la[1] = k.lb[0] = k.lb[1] = 0.f;
   k.mref[0] = k.mref[1] = 0.f;
-  k.mbase[0] = k.mbase[1] = 0.f;
+  k.mbase = 0.f;
   k.first[0] = k.first[1] = 1;
   k.clear_mask();
   k.kslot = k.wave_slot; k.vslot = RING * TILE + k.wave_slot;
@@ -397,16 +395,16 @@ template <int MODE> MMPL_DEV void w64_pass(Ctx& k) {
 
   k.plan(0);
   if constexpr (MODE == 0 && W64_ABL == 0) {
-    // FAST pass reference (header): the scores of KV tile 0 for both query blocks, their largest per query row + offset
+    // FAST pass reference (header): the scores of KV tile 0 for both query blocks, their largest per lane (= two query rows) + offset
     // becomes m_ref; it enters every later score through the C operand of the tile's first MFMA, so the pipeline below is untouched.
     sfor<16>([&k](auto gi) { k.template mfma_qk<0, decltype(gi)::value>(); });
     sfor<16>([&k](auto gi) { k.template mfma_qk<1, decltype(gi)::value>(); });
     k.mfma_write_pad();
-    float mx0 = k.template score_max<0>(), mx1 = k.template score_max<1>();
+    float mx = k.score_max();
     if (T > FAST_REF_TILES) {
       // ... and of KV tiles 1 .. 3, which the prologue above already sent on their way into ring slots 1 .. 3: four times the
       // sample for ~0.2 % more MFMAs per block (all full tiles strictly before the block's last one; T is block-uniform)
-      sfor<FAST_REF_TILES - 1>([&k, &mx0, &mx1](auto ei) {
+      sfor<FAST_REF_TILES - 1>([&k, &mx](auto ei) {
         constexpr int e = decltype(ei)::value + 1;
         // in flight, oldest first: K0 | K1 V0 | K2 V1 | K3 V2 (4 pieces each): K(e) has landed when at most 24 - 8 e are outstanding
         asm volatile("s_waitcnt vmcnt(%c0)\n\ts_barrier" ::"i"(24 - 8 * e) : "memory");
@@ -416,22 +414,16 @@ template <int MODE> MMPL_DEV void w64_pass(Ctx& k) {
         sfor<16>([&k](auto gi) { k.template mfma_qk<0, decltype(gi)::value>(); });
         sfor<16>([&k](auto gi) { k.template mfma_qk<1, decltype(gi)::value>(); });
         k.mfma_write_pad();
-        mx0 = fmaxf(mx0, k.template score_max<0>());
-        mx1 = fmaxf(mx1, k.template score_max<1>());
+        mx = fmaxf(mx, k.score_max());
       });
       k.kaddr = k.kbase;                                 // the K(0) fragments again: the pipeline starts from them
       sfor<16>([&k](auto gi) { k.template lds_k<decltype(gi)::value>(); });
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    // one reference per QUERY ROW (lanes l and l ^ 32 hold the two kv halves of a row's scores); round 4 shared one between the
-    // lane's two rows (blocks A and B), so a row whose own largest score sat far below its partner's lost that much of the window
-    // on the low side (profiles/r05a_attn_fast_window.log: a larger offset made MORE rows fail)
-    mx0 = fmaxf(mx0, __shfl_xor(mx0, 32, 64));
-    mx1 = fmaxf(mx1, __shfl_xor(mx1, 32, 64));
-    mx0 = fminf(fmaxf(mx0, -1e30f), 1e30f);            // (a NaN / inf score: the end-of-pass check fails and GENERAL takes over)
-    mx1 = fminf(fmaxf(mx1, -1e30f), 1e30f);
-    k.mref[0] = mx0 + FAST_REF_OFFSET; k.mref[1] = mx1 + FAST_REF_OFFSET;
-    k.mbase[0] = -k.mref[0]; k.mbase[1] = -k.mref[1];
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fminf(fmaxf(mx, -1e30f), 1e30f);              // (a NaN / inf score: the end-of-pass check fails and GENERAL takes over)
+    k.mref[0] = k.mref[1] = mx + FAST_REF_OFFSET;
+    k.mbase = -(mx + FAST_REF_OFFSET);
     k.masked = 1;                                      // make plan() rewrite the C-operand tile (mask of tile 0 included) on the new base
     k.plan(0);
   }

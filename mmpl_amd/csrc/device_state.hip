@@ -92,7 +92,6 @@ const MmplRuntimeConfig& mmpl_config() {
     c.gemm_group = num("MMPL_GEMM_GROUP", 0);
     c.gemm_pf = num("MMPL_GEMM_PF", 2);
     c.gemm_v8 = num("MMPL_GEMM_V8", -1);
-    c.gemm_v9 = num("MMPL_GEMM_V9", -1); c.gemm_v9_stagger = num("MMPL_GEMM_V9_STAGGER", 3);
     c.vae_no_fuse_norm = flag("MMPL_VAE_NO_FUSE_NORM");
     return c;
   }();

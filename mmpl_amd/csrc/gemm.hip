@@ -888,162 +888,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   else gemm128_tile<EPI>(g, smem, m0, n0);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// v9 "two blocks per CU" (round 5): the short-K / narrow GEMMs of Wan 1.3B (N = 1536, K = 1536: o, cross-q, cross-o; 258 / 222 / 78
-// tiles of 256 x 256).  With ONE 256 x 256 tile per CU and 24 k-tiles a launch is three chip-wide phases in lock step -- every
-// block waits for its first operand tiles, every block multiplies, every block reads its residual and stores 128 KiB -- and the
-// epilogue burst alone (64 MB through HBM) is as long as half the k loop: 680 TFLOP/s where the vendor's kernel does 918
-// (profiles/r04f_gemm_subtile_1p3B_shapes.log).  Here a block is 4 waves on a 256 x 128 tile (wave tile 128 x 64: v6's, same
-// MFMA shape, operand roles and per-accumulator k order -> the same bits) with a 3-stage ring of 32-wide k-steps in 72 KiB of
-// LDS and at most 256 registers per wave, so that TWO blocks share a CU, one wave of each per SIMD: while one block waits on
-// HBM (prologue, residual loads, stores) or at its barrier, the other one owns the matrix pipes -- v6's ping-pong between wave
-// groups, but between independent tiles, so that it also covers prologue and epilogue.  The blocks past the first one-per-CU wave
-// of the grid start g.pf_dist x ~4 us late (s_sleep 127 = 8128 cycles; launcher: MMPL_GEMM_V9_STAGGER) so that the two co-resident
-// blocks do not begin in lock step.
-// LDS image of a stage: rows are 64 bytes (32 bf16), two rows form a 128-byte super-row; 16-byte chunk q = 4 (row & 1) + c of
-// super-row sr sits at sr * 128 + ((q ^ (sr & 7)) << 4): the LDS-DMA writes it lane-linearly (lane l of a piece -> super-row
-// l >> 3, position l & 7, i.e. it FETCHES chunk (l & 7) ^ (l >> 3)), a fragment read (16 rows x 4 chunks) touches 8 super-rows x
-// 8 positions, every bank 4 times: conflict-free.
-constexpr int BM9 = 256, BN9 = 128, BK9 = 32;
-constexpr int A9_BYTES = BM9 * BK9 * 2, W9_BYTES = BN9 * BK9 * 2, STAGE9 = A9_BYTES + W9_BYTES, NST9 = 3, SMEM9 = NST9 * STAGE9;
-
-// tile idx of XCD `xcd`'s list -> (tm, tn, gsz) in the grouped-M / sweep-synchronous order of v6 with BN9-wide column panels
-struct Tile9 { int tm, tn; };
-MMPL_DEV Tile9 tile9_of(const GemmArgs& g, int xcd, int idx, int tiles_m, int tiles_n) {
-  const int GROUP = g.group, per_group = GROUP * tiles_n, nwg = tiles_m * tiles_n;
-  const int rounds = g.sync_sweeps ? (tiles_m / GROUP) >> 3 : 0;
-  const int dealt = rounds * per_group, left = nwg - 8 * dealt, lq = left >> 3, lr = left & 7;
-  int bid;
-  if (idx < dealt) bid = ((idx / per_group) * 8 + xcd) * per_group + idx % per_group;
-  else bid = 8 * dealt + (xcd < lr ? xcd * (lq + 1) : lr * (lq + 1) + (xcd - lr) * lq) + (idx - dealt);
-  const int first_m = (bid / per_group) * GROUP;
-  const int gsz = min(tiles_m - first_m, GROUP);
-  return Tile9{first_m + (bid % per_group) % gsz, (bid % per_group) / gsz};
-}
-MMPL_DEV int chunk9_all(const GemmArgs& g, int xcd, int tiles_m, int tiles_n) {
-  const int per_group = g.group * tiles_n, nwg = tiles_m * tiles_n;
-  const int rounds = g.sync_sweeps ? (tiles_m / g.group) >> 3 : 0;
-  const int dealt = rounds * per_group, left = nwg - 8 * dealt;
-  return dealt + (left >> 3) + (xcd < (left & 7) ? 1 : 0);
-}
-
-template <int EPI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_v9_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ int s_ticket;
-  const int tiles_m = (g.M + BM9 - 1) / BM9, tiles_n = (g.N + BN9 - 1) / BN9;
-  const bool persistent = g.tile_counter != nullptr;
-  const int my_xcd = blockIdx.x & 7;
-  const int chunk_all = chunk9_all(g, my_xcd, tiles_m, tiles_n);
-  const int chunk = g.splitk_s > 1 ? chunk_all - chunk_all % g.splitk_per : chunk_all;      // the partial last round belongs to the tail launch
-  const int blocks_x = (int)(gridDim.x >> 3) + (my_xcd < (int)(gridDim.x & 7) ? 1 : 0);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int frow = lane & 15, fchunk = lane >> 4;
-  // fragment read offsets within a stage (bytes): activation fragment i at a_off + 1024 i, weight fragment j at w_off + 1024 j
-  const int swz = (((frow & 1) * 4 + fchunk) ^ (frow >> 1)) << 4;
-  const int a_off = (64 * wm + (frow >> 1)) * 128 + swz;
-  const int w_off = A9_BYTES + (32 * wn + (frow >> 1)) * 128 + swz;
-  // LDS-DMA: lane l of a piece (16 rows) fetches chunk q = (l & 7) ^ (l >> 3) of super-row l >> 3: row 2 (l >> 3) + (q >> 2), 16-byte chunk q & 3
-  const int dq = (lane & 7) ^ (lane >> 3), drow = 2 * (lane >> 3) + (dq >> 2), dcol = (dq & 3) * 8;
-  const int nt = g.K / BK9;
-  if ((int)blockIdx.x >= 4 * g.splitk_per) {             // (splitk_per = slots per XCD = 2 x its CUs: block >= #CUs is some CU's second block)
-#pragma unroll 1
-    for (int i = 0; i < g.pf_dist; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-  for (;;) {
-    int idx = blockIdx.x >> 3;
-    if (persistent) {
-      if (threadIdx.x == 0) s_ticket = atomicAdd(g.tile_counter + my_xcd, 1);
-      __syncthreads();
-      const int ticket = s_ticket;
-      if (ticket >= chunk) {
-        if (ticket == chunk + blocks_x - 1 && threadIdx.x == 0) g.tile_counter[my_xcd] = 0;
-        return;
-      }
-      idx = ticket;
-    } else if (idx >= chunk) {
-      return;
-    }
-    const Tile9 tl = tile9_of(g, my_xcd, idx, tiles_m, tiles_n);
-    const int m0 = tl.tm * BM9, n0 = tl.tn * BN9;
-    uint32_t a_vo[4], w_vo[2];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) a_vo[q] = (uint32_t)(min(m0 + 16 * (4 * q + wave) + drow, g.M - 1) * g.lda + dcol) * 2u;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) w_vo[q] = (uint32_t)(min(n0 + 16 * (4 * q + wave) + drow, g.N - 1) * g.ldw + dcol) * 2u;
-    auto issue = [&](int t) {                            // this wave's 6 pieces of k-step t into stage t % 3
-      char* st = smem + (t % NST9) * STAGE9;
-      const bf16_t* ak = g.A + (size_t)t * BK9;
-      const bf16_t* wk = g.W + (size_t)t * BK9;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) glds16s(ak, a_vo[q], st + (4 * q + wave) * 1024);
-#pragma unroll
-      for (int q = 0; q < 2; ++q) glds16s(wk, w_vo[q], st + A9_BYTES + (4 * q + wave) * 1024);
-    };
-    f32x4 acc[2][4][4];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // every source offset is in its register HERE: hipcc otherwise sinks their arithmetic between the DMA statements, and a write to
-    // a register that one of ITS OWN earlier loads (the previous tile's epilogue) targeted gets an `s_waitcnt vmcnt(0)` in front of it
-    // -- which also drains the LDS-DMA pieces issued a moment earlier (one HBM round trip per tile, seen in the ISA)
-    asm volatile("" ::"v"(a_vo[0]), "v"(a_vo[1]), "v"(a_vo[2]), "v"(a_vo[3]), "v"(w_vo[0]), "v"(w_vo[1]));
-    issue(0);
-    if (nt > 1) issue(1);
-#pragma unroll 1
-    for (int t = 0; t < nt; ++t) {
-      // k-step t has landed when at most the 6 pieces of k-step t + 1 are outstanding; behind the barrier everybody is also done
-      // reading stage (t - 1) % 3, which k-step t + 2 goes into
-      if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (t + 2 < nt) issue(t + 2);
-      const char* st = smem + (t % NST9) * STAGE9;
-      bf16x8 af[8], wf[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(st + w_off + 1024 * j);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + a_off + 1024 * i);
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i >> 2][i & 3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i >> 2][i & 3][j], 0, 0, 0);
-    }
-    __builtin_amdgcn_s_barrier();                         // every wave is done with the ring: the epilogue stages through it
-    if (EPI != EPI_F32_SCALE && g.staged_epilogue) {
-      gemm_epilogue_staged<EPI>(g, acc, smem + wave * 16384, m0 + 128 * wm, n0 + 64 * wn, lane);
-    } else {
-      gemm_epilogue<EPI>(g, acc[0], m0 + 128 * wm, n0 + 64 * wn, frow, fchunk);
-      gemm_epilogue<EPI>(g, acc[1], m0 + 128 * wm + 64, n0 + 64 * wn, frow, fchunk);
-    }
-    if (!persistent) return;
-    __syncthreads();                                      // the ring (and s_ticket) are free again
-  }
-}
-
-// The partial last round of a v9 launch: every leftover 256 x 128 tile as two 128 x 128 halves on the small-tile bodies (RING: the
-// 4-stage DMA-ring body, one block per CU; else the register-staged body, two per CU) -- same bits as the main kernel's.
-template <int EPI, bool RING>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tail9_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tiles_m = (g.M + BM9 - 1) / BM9, tiles_n = (g.N + BN9 - 1) / BN9;
-  const int my_xcd = blockIdx.x & 7, r = blockIdx.x >> 3, t_local = r >> 1, half = r & 1;
-  const int chunk_all = chunk9_all(g, my_xcd, tiles_m, tiles_n);
-  const int idx = chunk_all - chunk_all % g.splitk_per + t_local;
-  if (idx >= chunk_all) return;
-  const Tile9 tl = tile9_of(g, my_xcd, idx, tiles_m, tiles_n);
-  const int m0 = tl.tm * BM9 + 128 * half, n0 = tl.tn * BN9;
-  if (m0 >= g.M || n0 >= g.N) return;
-  if constexpr (RING) gemm128_ring_tile<EPI>(g, smem, m0, n0);
-  else gemm128_tile<EPI>(g, smem, m0, n0);
-}
-
 #ifndef GEMM8_ABL
 #define GEMM8_ABL 0         // dev ablations of the v8 loop (results are garbage): 1 no LDS-DMA, 4 no fragment reads, 8 no barriers / waits
 #endif
@@ -1335,9 +1179,6 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
   if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v8_kernel<EPI>), 2 * STAGE4 + 2048); e != hipSuccess) return e;
   if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_tail128_kernel<EPI, true>), 8 * TILE_BYTES); e != hipSuccess) return e;
   if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_tail128_kernel<EPI, false>), 4 * TILE_BYTES); e != hipSuccess) return e;
-  if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_bf16_v9_kernel<EPI>), SMEM9); e != hipSuccess) return e;
-  if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_tail9_kernel<EPI, true>), 8 * TILE_BYTES); e != hipSuccess) return e;
-  if (hipError_t e = mmpl_dyn_smem_once(reinterpret_cast<const void*>(gemm_tail9_kernel<EPI, false>), 4 * TILE_BYTES); e != hipSuccess) return e;
   // main-launch kernel: v8 (one wave per SIMD, 128 x 128 per wave) or v6 (two, 128 x 64).  MMPL_GEMM_V8 = 1 / 0 forces it.
   const int env_v8 = mmpl_config().gemm_v8;
   const bool use_v8 = env_v8 >= 0 ? env_v8 != 0 : g.N >= 8192;       // the wide GEMMs (qkv, ffn0): profiles/r04c_gemm_v8_*.log
@@ -1369,37 +1210,6 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
   g2.pf_dist = rc.gemm_pf;
   g2.sync_sweeps = 1;
   const int per = mmpl_cus_per_xcd(), n_cu = 8 * per;
-  // v9 (256 x 128 tiles, two blocks per CU): the short-K narrow GEMMs (Wan 1.3B's o / cross-q / cross-o and the like), where one
-  // 256 x 256 tile per CU is three chip-wide phases in lock step.  MMPL_GEMM_V9 = 1 / 0 forces / forbids it.
-  {
-    const int env_v9 = rc.gemm_v9;
-    const bool use_v9 = env_v9 >= 0 ? env_v9 != 0 : (g.K <= 2048 && g.N <= 2048);
-    if (use_v9) {
-      const int tiles_n9 = (g.N + BN9 - 1) / BN9, tiles_m9 = (g.M + BM9 - 1) / BM9, tiles9 = tiles_m9 * tiles_n9, slots_x = 2 * per;
-      g2.group = env_group > 0 ? env_group : 4;
-      g2.pf_dist = rc.gemm_v9_stagger;                                  // (v9 reads it as its start stagger)
-      g2.splitk_s = 1; g2.splitk_tb = 0; g2.splitk_per = slots_x;
-      const int per_group = g2.group * tiles_n9, dealt = ((tiles_m9 / g2.group) >> 3) * per_group, left = tiles9 - 8 * dealt;
-      int tb = 0, main_tiles = 0;
-      for (int x = 0; x < 8; ++x) {
-        const int chunk = dealt + (left >> 3) + (x < (left & 7) ? 1 : 0);
-        tb = chunk % slots_x > tb ? chunk % slots_x : tb;
-        main_tiles += chunk - chunk % slots_x;
-      }
-      // the partial last round (at most half a round of slots) as 128 x 128 halves on the small-tile bodies, like the sub-tile launch below
-      if (g2.tile_counter && !rc.gemm_no_subtile && EPI != EPI_F32_SCALE && tb > 0 && 2 * tb <= slots_x && main_tiles > 0) {
-        g2.splitk_s = 2; g2.splitk_tb = tb;
-        hipLaunchKernelGGL(gemm_bf16_v9_kernel<EPI>, dim3(main_tiles < 2 * n_cu ? main_tiles : 2 * n_cu), dim3(256), SMEM9, s, g2);
-        if (2 * tb <= per) hipLaunchKernelGGL((gemm_tail9_kernel<EPI, true>), dim3(8 * tb * 2), dim3(256), 8 * TILE_BYTES, s, g2);
-        else hipLaunchKernelGGL((gemm_tail9_kernel<EPI, false>), dim3(8 * tb * 2), dim3(256), 4 * TILE_BYTES, s, g2);
-        return hipGetLastError();
-      }
-      const int blocks9 = g2.tile_counter && tiles9 > 2 * n_cu ? 2 * n_cu : tiles9;
-      if (blocks9 == tiles9) g2.tile_counter = nullptr;
-      hipLaunchKernelGGL(gemm_bf16_v9_kernel<EPI>, dim3(blocks9), dim3(256), SMEM9, s, g2);
-      return hipGetLastError();
-    }
-  }
   // Split-K launch for the partial last round.  With one tile per CU a GEMM of R * 256 + t tiles takes R + 1 rounds however small t
   // is (Wan 1.3B at 480p: 43 x 6 = 258 tiles for o / ffn2 at s1, 78 at s0; 14B / 720p s0: 580).  When every XCD's leftover (its
   // list length mod 32, same arithmetic as the kernel) fits one round in s >= 2 parts, the main launch stops at the full rounds and

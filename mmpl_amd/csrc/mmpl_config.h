@@ -14,8 +14,6 @@
 //   MMPL_GEMM_NO_SPLITK=1        v6 without the split-K launch for the partial last round of tiles
 //   MMPL_GEMM_NO_SUBTILE=1       short-K GEMMs without the 128 x 128 sub-tile launch for the partial last round of tiles
 //   MMPL_GEMM_V8=0|1             large GEMMs never / always on gemm_bf16_v8_kernel (default: the launcher's per-shape choice)
-//   MMPL_GEMM_V9=0|1             large GEMMs never / always on gemm_bf16_v9_kernel (256 x 128 tiles, two blocks per CU; default: short-K narrow GEMMs)
-//   MMPL_GEMM_V9_STAGGER=n       v9: the second block of every CU starts n x ~4 us late (default 3)
 //   MMPL_VAE_NO_FUSE_NORM=1      RMS_norm + SiLU of the 96-channel layers as its own pass instead of the producing conv's epilogue
 #pragma once
 
@@ -25,7 +23,6 @@ struct MmplRuntimeConfig {
   int gemm_group;      // 0 = launcher's choice
   int gemm_pf;         // k-tiles
   int gemm_v8;         // -1 = launcher's choice, 0 / 1 = never / always the one-wave-per-SIMD kernel for the main launch
-  int gemm_v9, gemm_v9_stagger;   // -1 = launcher's choice, 0 / 1 = never / always the two-blocks-per-CU kernel; its start stagger
   bool vae_no_fuse_norm;
 };
 const MmplRuntimeConfig& mmpl_config();

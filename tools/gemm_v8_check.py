@@ -1,8 +1,6 @@
 #!/usr/bin/env python3
-"""dev: sha256 of the large-GEMM outputs per (shape, epilogue, entry point).  Run once with MMPL_GEMM_V8=0 and once with =1 (or
-MMPL_GEMM_V9=0 / 1) and diff the two listings: gemm_bf16_v8_kernel and gemm_bf16_v9_kernel issue the same MFMAs in the same
-per-accumulator order as v6, so every line must agree (except the `scratch` column of a K >= 4096 shape under MMPL_GEMM_V9=1: v9
-has no split-K tail, whose partial sums are added in another -- fixed -- order)."""
+"""dev: sha256 of the large-GEMM outputs per (shape, epilogue, entry point).  Run once with MMPL_GEMM_V8=0 and once with =1 and diff the
+two listings: gemm_bf16_v8_kernel issues the same MFMAs in the same per-accumulator order as v6, so every line must agree."""
 import hashlib
 import math
 import os

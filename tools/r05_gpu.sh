@@ -4,6 +4,8 @@
 # Steps that rebuild the library with experiment defines (MMPL_EXTRA_HIPCC_FLAGS) restore the plain build when they are done.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 tag=$1; shift; out=gpurun_out/$tag; mkdir -p $out
+ulimit -c 0                                     # a faulting kernel must not fill the box's disk with core files (it did once: r05b)
+clean_cores() { rm -f gpucore.* core.* /tmp/gpucore.* /tmp/core.* 2>/dev/null; }
 BIG="qkv:25200:15360:5120:0,o:25200:5120:5120:3,ffn0:25200:13824:5120:1,ffn2:25200:5120:13824:3"
 S13="qkv_s1:10920:4608:1536:0,o_s1:10920:1536:1536:3,ffn0_s1:10920:8960:1536:1,ffn2_s1:10920:1536:8960:3,qkv_s2:9360:4608:1536:0,o_s2:9360:1536:1536:3,ffn0_s2:9360:8960:1536:1,ffn2_s2:9360:1536:8960:3,qkv_s0:3120:4608:1536:0,o_s0:3120:1536:1536:3"
 build() { MMPL_EXTRA_HIPCC_FLAGS="$1" python -m mmpl_amd.build > $out/build.log 2>&1 || { echo "BUILD FAILED ($1)"; tail -5 $out/build.log; }; }
@@ -56,29 +58,28 @@ for step in "$@"; do
         for g in 8 5; do python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae --heavy-tail --heavy-tail-gain $g > $out/refoff_tmp.json 2>> $out/bench.err; line $out/refoff_tmp.json "[$f] heavy-tail x$g" >> $out/attn_fast_window.log; done
         python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae --attn-stats > $out/refoff_tmp.json 2>> $out/bench.err; line $out/refoff_tmp.json "[$f] default weights" >> $out/attn_fast_window.log
       done; build ""; cat $out/attn_fast_window.log ;;
-    v9)          # gemm_bf16_v9_kernel (256 x 128 tiles, two blocks per CU): bit-identity with v6 / v8, the GEMM tests on it, timing on the 1.3B shapes
-      MMPL_GEMM_V9=0 timeout 600 python tools/gemm_v8_check.py > $out/gemm_v9off_sha.log 2>&1
-      MMPL_GEMM_V9=1 timeout 600 python tools/gemm_v8_check.py > $out/gemm_v9on_sha.log 2>&1
-      diff $out/gemm_v9off_sha.log $out/gemm_v9on_sha.log > $out/gemm_v9_vs_v6.diff && echo "v9 == v6 / v8 bit for bit on every line" | tee -a $out/gemm_v9_vs_v6.diff; head -20 $out/gemm_v9_vs_v6.diff
-      MMPL_GEMM_V9=1 python -m pytest tests/test_kernels_gpu.py -m gpu -q -k "gemm" 2>&1 | tail -3 > $out/test_gemm_v9.log; cat $out/test_gemm_v9.log
-      for e in "MMPL_GEMM_V9=0" "MMPL_GEMM_V9=1 MMPL_GEMM_V9_STAGGER=0" "MMPL_GEMM_V9=1 MMPL_GEMM_V9_STAGGER=2" "MMPL_GEMM_V9=1 MMPL_GEMM_V9_STAGGER=4" "MMPL_GEMM_V9=1 MMPL_GEMM_V9_STAGGER=8" "A=0" "MMPL_GEMM_V9=0"; do
-        echo "== $e" >> $out/gemm_v9_timing.log; env $e BENCH_SHAPES=$S13 timeout 300 python tools/bench_kernels.py gemm --iters 20 2>&1 | grep "^gemm" >> $out/gemm_v9_timing.log
-      done
-      for e in "MMPL_GEMM_V9=0" "MMPL_GEMM_V9=1" "MMPL_GEMM_V9=0" "MMPL_GEMM_V9=1"; do      # ... and, for the record, on the 14B / 720p block shapes
-        echo "== $e (14B / 720p shapes)" >> $out/gemm_v9_timing.log; env $e BENCH_SHAPES=$BIG timeout 300 python tools/bench_kernels.py gemm --iters 5 2>&1 | grep "^gemm" >> $out/gemm_v9_timing.log
-      done; cat $out/gemm_v9_timing.log ;;
-    bench13ab)   # 1.3B / 480p in situ: v9 off / default / off / default
-      for e in "MMPL_GEMM_V9=0" "A=0" "MMPL_GEMM_V9=0" "A=0"; do env $e python bench.py --model 1.3B --res 480p --no-cpu-baseline --no-vae --profile-all > $out/b13_tmp.json 2>> $out/bench.err; line $out/b13_tmp.json "[$e]" >> $out/bench_1p3B_v9_ab.log; done; cat $out/bench_1p3B_v9_ab.log ;;
-    refoff2)     # the same with ONE reference per query row (round 5 kernel): offsets 64 (shipping window) / 88 / 100
-      for f in "" "-DW64_REF_OFFSET=88 -DW64_LMIN_EXP=124" "-DW64_REF_OFFSET=100 -DW64_LMIN_EXP=124"; do
-        build "$f"
-        for g in 8 5; do python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae --heavy-tail --heavy-tail-gain $g > $out/refoff_tmp.json 2>> $out/bench.err; line $out/refoff_tmp.json "per-row reference [$f] heavy-tail x$g" >> $out/attn_fast_window_per_row.log; done
-        python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae --attn-stats > $out/refoff_tmp.json 2>> $out/bench.err; line $out/refoff_tmp.json "per-row reference [$f] default weights" >> $out/attn_fast_window_per_row.log
-      done; build ""; cat $out/attn_fast_window_per_row.log ;;
     kerneltests)
       python -m pytest tests/test_kernels_gpu.py tests/test_wavefront_gpu.py tests/test_dit_forward_gpu.py tests/test_fullsize_gpu.py -m gpu -q -s > $out/kerneltests.log 2>&1; echo "rc=$?" >> $out/kerneltests.log
       grep -E "hand-off for chunk|deferred at|passed|failed|rc=|Error" $out/kerneltests.log | tail -20 ;;
+    conc)        # cond | uncond forwards as two parallel branches of the step graph: 14B / 720p and 1.3B / 480p, alternating with the default
+      for a in "" "--concurrent-cfg" "" "--concurrent-cfg"; do
+        python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae $a > $out/conc_tmp.json 2>> $out/bench.err; line $out/conc_tmp.json "14B/720p [$a]" >> $out/bench_concurrent_cfg_ab.log
+        python bench.py --model 1.3B --res 480p --steps 16 --warmup 8 --no-cpu-baseline --no-vae $a > $out/conc_tmp.json 2>> $out/bench.err; line $out/conc_tmp.json "1.3B/480p [$a]" >> $out/bench_concurrent_cfg_ab.log
+      done; cat $out/bench_concurrent_cfg_ab.log ;;
+    storepol)    # 1.3B / 480p: plain C stores (may stay in the Infinity Cache for the next kernel) vs the shipping nt stores
+      for f in "" "-DGEMM6_STORE=0" "" "-DGEMM6_STORE=0"; do
+        build "$f"; python bench.py --model 1.3B --res 480p --steps 16 --warmup 8 --no-cpu-baseline --no-vae --profile-all > $out/sp_tmp.json 2>> $out/bench.err; line $out/sp_tmp.json "1.3B/480p [$f]" >> $out/gemm_store_policy_1p3B.log
+      done
+      build "-DGEMM6_STORE=0"; python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae --profile-all > $out/sp_tmp.json 2>> $out/bench.err; line $out/sp_tmp.json "14B/720p [-DGEMM6_STORE=0]" >> $out/gemm_store_policy_1p3B.log
+      build ""; python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae --profile-all > $out/sp_tmp.json 2>> $out/bench.err; line $out/sp_tmp.json "14B/720p []" >> $out/gemm_store_policy_1p3B.log
+      cat $out/gemm_store_policy_1p3B.log ;;
+    refoff3)     # FAST window (shared reference): offset 64 / 72 / 80 / 88 with the lower bound at 2^-124
+      for o in 64 72 80 88; do
+        build "-DW64_REF_OFFSET=$o -DW64_LMIN_EXP=124"
+        for g in 8 5; do python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae --heavy-tail --heavy-tail-gain $g > $out/refoff_tmp.json 2>> $out/bench.err; line $out/refoff_tmp.json "offset $o heavy-tail x$g" >> $out/attn_fast_window_offsets.log; done
+      done; build ""; cat $out/attn_fast_window_offsets.log ;;
     *) echo "unknown step $step" ;;
   esac
+  clean_cores
 done
 ls -la $out
