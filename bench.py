@@ -85,8 +85,10 @@ def parse():
     ap.add_argument("--no-cfg-split", action="store_true", help="N chunk lanes whatever N is")
     ap.add_argument("--eager", action="store_true", help="time plain launches instead of one hipGraph replay per step")
     ap.add_argument("--concurrent-cfg", action="store_true",
-                    help="the cond and the uncond forward of a step as two PARALLEL branches of the step graph (a second stream, a private "
-                         "workspace): the tail of one branch's kernels (partial last rounds, split tails, launch gaps) is filled by the other's")
+                    help="ALWAYS the cond and the uncond forward of a step as two PARALLEL branches of the step graph (a second stream, a private "
+                         "workspace): the tail of one branch's kernels (partial last rounds, split tails, launch gaps) is filled by the other's.  "
+                         "Default: per stage where it pays (mmpl_amd.stage_plan.concurrent_cfg_pays -- what the pipeline does)")
+    ap.add_argument("--no-concurrent-cfg", action="store_true", help="never: the two forwards one after the other on one stream")
     ap.add_argument("--wavefront-chunks", type=int, default=0,
                     help="C > 0: instead of K rotating steps, run ONE video of C chunks through the real pipeline and the real dependency chain "
                          "(chunk c on lane c %% lanes, RCCL anchor hand-off after the anchor stage, VAE consumer transform) and report the MEASURED "
@@ -579,11 +581,14 @@ def main():
             st["t"].fill_(float(sched.timesteps[0]))
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            if args.concurrent_cfg and "ws2" not in st:
-                st["ws2"] = torch.empty(eng.workspace(len(st["frames"])).numel(), dtype=torch.uint8, device=dev)
+            from mmpl_amd.stage_plan import concurrent_cfg_pays
+            st["concurrent"] = (args.concurrent_cfg or concurrent_cfg_pays(len(st["frames"]) * S, eng.dim)) and not args.no_concurrent_cfg
+            if st["concurrent"] and "ws2" not in st:
+                st["ws2"] = eng.second_workspace(len(st["frames"]))
                 st["side"] = torch.cuda.Stream(device=dev)
+                torch.cuda.synchronize()
             with torch.cuda.graph(g):
-                if args.concurrent_cfg:
+                if st["concurrent"]:
                     x_in = xin(st)
                     main = torch.cuda.current_stream()
                     st["side"].wait_stream(main)                      # fork: the uncond branch on a second captured stream
@@ -599,6 +604,7 @@ def main():
                         eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out, cross_rows=crows)
                 sched.step_cfg_table(st["fc"], st["fu"], st["lat"], st["t"])
             st["graph"], st["replays"] = g, 0
+    concurrent_stages = [i for i, st in enumerate(stage_state) if st.get("concurrent")]
     if pair is not None and not args.eager:
         # CFG pair: each rank's forward is a hipGraph (the per-step exchange of the two flow predictions is issued by the host)
         for st in stage_state:
@@ -639,7 +645,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     step_s = [e0.elapsed_time(e1) * 1e-3 for e0, e1 in ev]
-    attn_blocks, attn_redone = eng.read_attn_stats() if attn_stats is not None else (None, None)   # of the timed region (graph replays included)
+    attn_blocks, attn_redone, attn_waves_bad = eng.read_attn_stats() if attn_stats is not None else (None, None, None)   # of the timed region (graph replays included)
     # ---- eager pass (after the timed region when that one replayed graphs): one rotation of the four stages with a hipEvent
     # pair around every self-attention launch (all kernel classes with --profile-all) -> `eager` figures and `roofline`
     eager_step_s = None
@@ -718,7 +724,8 @@ def main():
                                    f"rotating the four {args.mode.upper()} denoise stages {stage_shapes} (query, attended frames); one "
                                    f"21-latent-frame chunk per GPU = 204 step-equivalents",
                        "frame_seqlen": S, "latent_hw": [lat_h, lat_w], "sampling_steps": 50, "guidance_scale": 5.0,
-                       "timed_path": ("one hipGraph replay per denoise step (2 DiT forwards" + (" as two parallel branches" if args.concurrent_cfg else "") +
+                       "timed_path": ("one hipGraph replay per denoise step (2 DiT forwards" +
+                                      (f", as two parallel graph branches in stages {concurrent_stages}" if concurrent_stages else "") +
                                       " + fused CFG/UniPC, device-resident step tables)"
                                       if use_graph else ("one hipGraph replay per forward + host-issued flow exchange + fused CFG/UniPC launch"
                                                          if pair is not None and not args.eager else "eager launches")),
@@ -737,7 +744,9 @@ def main():
             # data dependence of the self-attention kernel IN THE TIMED REGION: 256-row query blocks whose max-free FAST softmax pass
             # overflowed / underflowed and were redone by the GENERAL pass (attn_w64.hip); caches hold K / V written by real forwards
             **({"attn_blocks": attn_blocks, "attn_blocks_redone": attn_redone,
-                "attn_blocks_redone_fraction": (attn_redone / attn_blocks) if attn_blocks else None} if attn_stats is not None else {}),
+                "attn_blocks_redone_fraction": (attn_redone / attn_blocks) if attn_blocks else None,
+                # per WAVE (64 of a block's 256 query rows): how many held a failing row themselves -- what a finer redo unit would pay for
+                "attn_waves_failed_fraction": (attn_waves_bad / (4.0 * attn_blocks)) if attn_blocks else None} if attn_stats is not None else {}),
             **({"weights": f"heavy-tailed synthetic (QK-norm gains x{args.heavy_tail_gain:g}, six massive-activation channels): NOT the headline workload"}
                if args.heavy_tail else {}),
         }

@@ -65,8 +65,9 @@ int mmpl_dit_set_image_kv(MmplDit* h, const void* img_k, const void* img_v, int 
 
 /* Optional diagnostics of the self-attention kernel's data dependence.  attn_w64_kernel runs a max-free FAST softmax pass per
  * 256-row query block and redoes the block with the GENERAL (running-reference) pass if any row sum left [2^-40, 2^100].
- * stats_dev: 2 x uint64 in device memory (borrowed; zero them yourself), incremented by every self-attention launch of
- * mmpl_dit_forward on this handle, inside hipGraph replays too: [0] += blocks run, [1] += blocks redone.  NULL switches it off. */
+ * stats_dev: 3 x uint64 in device memory (borrowed; zero them yourself), incremented by every self-attention launch of
+ * mmpl_dit_forward on this handle, inside hipGraph replays too: [0] += blocks run, [1] += blocks redone, [2] += waves (64 of a
+ * block's 256 query rows) that held a failing row themselves -- the unit a finer-grained redo would pay for.  NULL switches it off. */
 int mmpl_dit_set_attn_stats(MmplDit* h, void* stats_dev);
 
 /* CausalFPSWanModel._forward_inference (causal_fps_model.py:708-837) behind WanFPSWrapper.forward

@@ -68,8 +68,8 @@ struct AttnArgs {
   // attn_fwd_kernel with ONE page only: the page's last row stands for `last_row_copies` identical keys (same K row, same V row):
   // its score gets + ln(copies) / scale, i.e. its softmax weight is multiplied by copies.  0 / 1 = a plain row.
   int last_row_copies;
-  // attn_w64_kernel, optional: two device counters {blocks run, blocks whose FAST pass failed and were redone by the GENERAL pass}
-  // (one atomic per block; how data-dependent is the kernel's time on THIS input? -- bench.py --heavy-tail)
+  // attn_w64_kernel, optional: three device counters {blocks run, blocks whose FAST pass failed and were redone by the GENERAL pass,
+  // WAVES (64 query rows) that held a failing row themselves} (how data-dependent is the kernel's time on THIS input? -- bench.py --heavy-tail)
   unsigned long long* redo_stats;
 };
 // Work item `local` of XCD `xcd` -> (head, query block) for attn_w64_kernel / attn_merge_kernel (the hardware deals workgroups

@@ -63,6 +63,7 @@ class DitEngine:
         self._h = h
         self._weights: List[torch.Tensor] = []
         self._ws: Dict[int, torch.Tensor] = {}
+        self._ws2: Optional[torch.Tensor] = None
         self._ctx_ws: Optional[torch.Tensor] = None
         self._i2v_w: Optional[dict] = None                 # img_emb + per-layer k_img / v_img / norm_k_img (model_type 'i2v')
         self._img_kv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
@@ -121,12 +122,13 @@ class DitEngine:
     # ------------------------------------------------------------------ diagnostics
     def enable_attn_stats(self) -> torch.Tensor:
         """Count the self-attention kernel's query blocks and how many of them the max-free FAST softmax pass could not hold
-        (redone by the GENERAL pass): int64 [2] on the device = {blocks, blocks redone}, incremented by every later forward.
+        (redone by the GENERAL pass): int64 [3] on the device = {blocks, blocks redone, waves (64 rows) that held a failing row},
+        incremented by every later forward.
         The counter's address is a kernel argument: a hipGraph captured while stats are on keeps counting on every replay
         whatever `disable_attn_stats` says later, and one captured while they are off never counts.  One atomic per 256-row
         block; `bench.py` switches it on for its diagnostic modes only."""
         if self._attn_stats is None:
-            self._attn_stats = torch.zeros(2, dtype=torch.int64, device=self.device)
+            self._attn_stats = torch.zeros(3, dtype=torch.int64, device=self.device)
         _lib.check(self._lib.mmpl_dit_set_attn_stats(self._h, _lib.ptr(self._attn_stats)), "mmpl_dit_set_attn_stats")
         return self._attn_stats
 
@@ -134,13 +136,14 @@ class DitEngine:
         """Later eager forwards and later captures stop counting (graphs captured before keep their setting)."""
         _lib.check(self._lib.mmpl_dit_set_attn_stats(self._h, None), "mmpl_dit_set_attn_stats")
 
-    def read_attn_stats(self, reset: bool = False) -> Tuple[int, int]:
+    def read_attn_stats(self, reset: bool = False) -> Tuple[int, int, int]:
+        """(blocks run, blocks redone, waves that held a failing row) since the counters were last zeroed."""
         if self._attn_stats is None:
             raise RuntimeError("DitEngine.read_attn_stats: enable_attn_stats() was never called on this engine")
-        blocks, redone = (int(v) for v in self._attn_stats.cpu())
+        blocks, redone, waves = (int(v) for v in self._attn_stats.cpu())
         if reset:
             self._attn_stats.zero_()
-        return blocks, redone
+        return blocks, redone, waves
 
     # ------------------------------------------------------------------ caches
     def new_kv_cache(self, n_slots: int = 15) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -214,6 +217,14 @@ class DitEngine:
             else:
                 self._ws[n_frames] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._ws[n_frames]
+
+    def second_workspace(self, n_frames: int) -> torch.Tensor:
+        """A private scratch buffer for a forward that runs CONCURRENTLY with another one of this engine (the uncond branch of a
+        denoise step on a second stream): one buffer, sized for the largest stage seen so far, allocated outside any capture."""
+        nbytes = self._lib.mmpl_dit_workspace_bytes(self._h, n_frames)
+        if self._ws2 is None or self._ws2.numel() < nbytes:
+            self._ws2 = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws2
 
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, t: torch.Tensor, frame_ids: Sequence[int], write_slots: Sequence[int],

@@ -69,6 +69,11 @@ class CausalFPSInferencePipeline(torch.nn.Module):
         self.renoise_override = None      # tests: {frame: [1,16,h,w]} instead of torch.randn_like draws
         self.use_graphs = True            # one hipGraph per (stage, cond|uncond) forward, replayed 50 + 1 times
         self.step_graphs = True           # ... and one per whole denoise step (2 forwards + CFG/UniPC) for the 50 steps
+        # the cond and the uncond forward of a step as two PARALLEL branches of the step graph (second stream, private workspace):
+        # None = where it pays (mmpl_amd.stage_plan.concurrent_cfg_pays: small stages / small models), True / False = always / never.
+        # Same kernels, same arguments, same bits either way (tests/test_pipeline_gpu.py).
+        self.concurrent_cfg: Optional[bool] = None
+        self._side_stream = None
         self.cfg_pair = None              # mmpl_amd.handoff.CfgPair: this rank runs only the cond (role 0) / uncond (role 1) branch
 
         # ---- "add new noise on previous frames" schedule (casual_fps_inference.py:93-108); the randint keeps the
@@ -82,11 +87,11 @@ class CausalFPSInferencePipeline(torch.nn.Module):
         return self
 
     # ------------------------------------------------------------------------------------------------------------
-    def _forward(self, latents, cond, timestep, kv, cross, frames, out=None):
+    def _forward(self, latents, cond, timestep, kv, cross, frames, out=None, workspace=None):
         S = self.frame_seq_length
         starts = [f * S for f in frames]
         return self.generator_cond(noisy_image_or_video=latents, conditional_dict=cond, timestep=timestep, kv_cache=kv,
-                                   crossattn_cache=cross, current_start=starts, cache_start=starts, out=out)[0]
+                                   crossattn_cache=cross, current_start=starts, cache_start=starts, out=out, workspace=workspace)[0]
 
     def _branches(self, cond, uncond):
         """[(conditional_dict, kv_cache, crossattn_cache, index into the flow pair)] this rank computes."""
@@ -212,10 +217,30 @@ class CausalFPSInferencePipeline(torch.nn.Module):
                         sample_scheduler.build_step_table(self.args.guidance_scale, dev)
                         sample_scheduler._ensure_state(latents)
                         torch.cuda.synchronize(dev)
+                        engine = self.generator_cond.engine
+                        concurrent = self.concurrent_cfg
+                        if concurrent is None:
+                            from ..stage_plan import concurrent_cfg_pays
+                            concurrent = concurrent_cfg_pays(len(frames) * S, engine.dim)
+                        ws2 = None
+                        if concurrent:                                      # (allocations and the stream: outside the capture)
+                            ws2 = engine.second_workspace(len(frames))
+                            if self._side_stream is None:
+                                self._side_stream = torch.cuda.Stream(device=dev)
+                            torch.cuda.synchronize(dev)
                         step_graph = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(step_graph):
-                            for (d, kv, cross, _), o in zip(branches, outs):
-                                self._forward(latents, d, timestep, kv, cross, frames, o)
+                            if concurrent:
+                                main, side = torch.cuda.current_stream(dev), self._side_stream
+                                (d0, kv0, cr0, _), (d1, kv1, cr1, _) = branches
+                                side.wait_stream(main)                          # fork
+                                self._forward(latents, d0, timestep, kv0, cr0, frames, outs[0])
+                                with torch.cuda.stream(side):
+                                    self._forward(latents, d1, timestep, kv1, cr1, frames, outs[1], workspace=ws2)
+                                main.wait_stream(side)                          # join: the CFG / UniPC update needs both
+                            else:
+                                for (d, kv, cross, _), o in zip(branches, outs):
+                                    self._forward(latents, d, timestep, kv, cross, frames, o)
                             sample_scheduler.step_cfg_table(flow[0], flow[1], latents, timestep)
                 if step_graph is not None:
                     timestep.fill_(float(sample_scheduler.timesteps[0]))

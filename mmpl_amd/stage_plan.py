@@ -110,3 +110,16 @@ def assemble_chunk_seconds(step_seconds, first_step_index: int, stage_flops, ste
     rate = sum(stage_flops[k] for k in seen) / sum(sum(per_stage[k]) / len(per_stage[k]) for k in seen)
     stage_s = [sum(per_stage[k]) / len(per_stage[k]) if per_stage[k] else stage_flops[k] / rate for k in range(4)]
     return stage_s, float(steps_per_stage) * sum(stage_s)
+
+
+# Measured on MI355X (profiles/r05c_bench_concurrent_cfg_ab.log, r05d_*): with the two CFG branches of a denoise step captured as
+# PARALLEL branches of the step graph, the tails of one branch's kernels (partial last rounds of tiles, split-KV tails, launch gaps,
+# the chip-wide prologue / epilogue phases of short-K GEMMs) are filled by the other's.  Wan 1.3B at 480p (query rows x dim = 4.8 ...
+# 16.8 M): -5.6 ... -17 % per stage, -8.4 % per step; Wan 14B at 720p: the 2-frame stage (36.9 M) -1.3 %, the 6- and 7-frame
+# stages (111 ... 129 M) +0.6 ... +1.7 % (two long kernels contending for the same CUs and L2 lose more than their tails are worth).
+CONCURRENT_CFG_MAX_ROWS_X_DIM = 48e6
+
+
+def concurrent_cfg_pays(n_query_rows: int, dim: int) -> bool:
+    """Should the cond and the uncond forward of a denoise step run as parallel graph branches?  (bit-identical either way)"""
+    return float(n_query_rows) * float(dim) <= CONCURRENT_CFG_MAX_ROWS_X_DIM

@@ -274,3 +274,45 @@ def test_forward_bits_do_not_depend_on_where_the_workspace_lies():
         outs.append(y.clone())
     assert torch.isfinite(outs[0].float()).all()
     assert torch.equal(outs[0], outs[1])
+
+
+def test_attention_redo_counters_blocks_and_waves():
+    """mmpl_dit_set_attn_stats: {query blocks run, blocks whose max-free FAST pass failed and were redone, WAVES (64 of a block's 256
+    rows) that held a failing row themselves}.  Default weights: nothing fails.  QK-norm gains x 12 (logit spread far beyond the FAST
+    window): blocks fail, each failing block has 1..4 failing waves, and the forward is still finite (the GENERAL pass took over)."""
+    from mmpl_amd.dit import DitEngine
+    from mmpl_amd.synthetic import WAN_CONFIGS, dit_state_dict, philox_normal
+    cfg = WAN_CONFIGS["tiny"]
+    frames = [0, 1]
+    x = philox_normal([2, 16, 16, 24], 7).cuda()
+    t = torch.full([2], 700.0, dtype=torch.float32).cuda()
+    ctx = philox_normal([512, cfg["text_dim"]], 41)
+    seen = {}
+    for gain in (1.0, 12.0):
+        sd = dit_state_dict(cfg, seed=3)
+        for l in range(cfg["num_layers"]):
+            for k in ("self_attn.norm_q.weight", "self_attn.norm_k.weight"):
+                sd[f"blocks.{l}.{k}"] = (sd[f"blocks.{l}.{k}"].float() * gain).to(torch.bfloat16)
+        eng = DitEngine(cfg, 16, 24, "cuda:0")
+        eng.load_state_dict(sd)
+        with pytest.raises(RuntimeError, match="never called"):
+            eng.read_attn_stats()
+        eng.enable_attn_stats()
+        kv = eng.precompute_context(ctx.cuda())
+        kc, vc = eng.new_kv_cache(15)
+        y = eng.forward(x, t, frames, [0, 1], [0, 1], kc, vc, kv[0], kv[1], cross_rows=kv.rows)
+        torch.cuda.synchronize()
+        blocks, redone, waves = eng.read_attn_stats(reset=True)
+        assert eng.read_attn_stats() == (0, 0, 0)
+        assert torch.isfinite(y.float()).all()
+        n_qb = -(-2 * eng.S // 256)
+        items = cfg["num_layers"] * cfg["num_heads"] * n_qb                # (a split-KV tail round runs a query block as 2-4 blocks)
+        assert items <= blocks <= 4 * items, (blocks, items)
+        assert 0 <= redone <= blocks and redone <= waves <= 4 * redone
+        seen[gain] = (blocks, redone, waves)
+        eng.disable_attn_stats()
+        eng.forward(x, t, frames, [0, 1], [0, 1], kc, vc, kv[0], kv[1], cross_rows=kv.rows)
+        torch.cuda.synchronize()
+        assert eng.read_attn_stats() == (0, 0, 0)                     # off: later eager forwards do not count
+    print("attention redo counters {gain: (blocks, blocks redone, waves with a failing row)}:", seen)
+    assert seen[1.0][1] == 0 and seen[12.0][1] > 0

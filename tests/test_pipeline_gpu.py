@@ -139,3 +139,28 @@ def test_cli_i2v_synthetic(tmp_path):
               "--image", str(img), "--output_folder", str(out)])
     v = torch.load(out / "0-0.pt")
     assert v.shape == (81, 128, 192, 3)
+
+
+def test_concurrent_cfg_branches_are_bit_identical_to_sequential():
+    """Round 5: the cond and the uncond forward of a denoise step as two PARALLEL branches of the step hipGraph (second stream, private
+    workspace; where mmpl_amd.stage_plan.concurrent_cfg_pays says so -- every stage of this small model).  Same kernels, same
+    arguments: the chunk must not change by a bit, first chunk and chunk >= 2."""
+    from mmpl_amd.synthetic import philox_normal
+    from mmpl_amd.stage_plan import concurrent_cfg_pays
+    pipe, *_ = _setup("t2v", steps=3)
+    assert pipe.concurrent_cfg is None and concurrent_cfg_pays(7 * pipe.frame_seq_length, pipe.generator_cond.engine.dim)
+    assert not concurrent_cfg_pays(7 * 3600, 5120) and concurrent_cfg_pays(7 * 1560, 1536)        # 14B / 720p anchors: no; 1.3B / 480p: yes
+    noise = philox_normal([1, 21, 16, *LAT], 23)
+    renoise = {f: philox_normal([1, 16, *LAT], 100 + f) for f in (4, 9, 13, 18)}
+    pipe.renoise_override = {k: v.cuda() for k, v in renoise.items()}
+    init = philox_normal([1, 2, 16, *LAT], 55)
+    res = {}
+    for mode in (False, True, None):
+        pipe.concurrent_cfg = mode
+        _, a = pipe.inference(noise.cuda(), ["a cat"], return_latents=True, decode=False)
+        _, b = pipe.inference(noise.cuda(), ["a cat"], initial_latent=init.cuda(), return_latents=True, decode=False)
+        torch.cuda.synchronize()
+        res[mode] = (a.clone(), b.clone())
+    assert pipe._side_stream is not None
+    for mode in (True, None):
+        assert torch.equal(res[mode][0], res[False][0]) and torch.equal(res[mode][1], res[False][1]), mode

@@ -78,6 +78,17 @@ for step in "$@"; do
         build "-DW64_REF_OFFSET=$o -DW64_LMIN_EXP=124"
         for g in 8 5; do python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae --heavy-tail --heavy-tail-gain $g > $out/refoff_tmp.json 2>> $out/bench.err; line $out/refoff_tmp.json "offset $o heavy-tail x$g" >> $out/attn_fast_window_offsets.log; done
       done; build ""; cat $out/attn_fast_window_offsets.log ;;
+    conc2)       # the shipped rule (concurrent CFG branches per stage where rows x dim <= 48 M) against never / always: 14B at 720p and 480p, 1.3B
+      for cfg in "--model 14B --res 720p --steps 8 --warmup 4" "--model 14B --res 480p --steps 8 --warmup 4" "--model 1.3B --res 480p --steps 16 --warmup 8"; do
+        for a in "--no-concurrent-cfg" "" "--concurrent-cfg" "--no-concurrent-cfg" ""; do
+          python bench.py $cfg --no-cpu-baseline --no-vae $a > $out/conc_tmp.json 2>> $out/bench.err; line $out/conc_tmp.json "[$cfg] [$a]" >> $out/bench_concurrent_cfg_rule.log
+        done
+      done; cat $out/bench_concurrent_cfg_rule.log ;;
+    pipetests)
+      python -m pytest tests/test_pipeline_gpu.py tests/test_dit_forward_gpu.py tests/test_trajectory_gpu.py tests/test_i2v_pipeline_gpu.py tests/test_cfg_pair_gpu.py -m gpu -q -s > $out/pipetests.log 2>&1; echo "rc=$?" >> $out/pipetests.log
+      grep -E "408 forwards|24 forwards|50 steps|i2v|redo counters|passed|failed|rc=|Error" $out/pipetests.log | tail -30 ;;
+    chunk13)
+      python tools/full_chunk.py --model 1.3B --res 480p > $out/full_chunk_1p3B_480p.json 2>> $out/bench.err; tail -c 500 $out/full_chunk_1p3B_480p.json ;;
     *) echo "unknown step $step" ;;
   esac
   clean_cores
