@@ -418,42 +418,61 @@ MMPL_DEV void glds4s(const void* base, uint32_t voff, char* lds) {
 // (16-byte chunk c of row r at r*128 + 16*(c ^ (r & 7))), and is read back row-major: a lane owns 8 consecutive columns of
 // a row -> 16-byte residual / gate loads and stores, 128 contiguous bytes per row.  Every residual load of the sub-tile is
 // issued before the first store (the residual usually IS the output buffer) and all of them are in flight at once.
+struct EpiIn {                 // what a wave's 128 x 64 sub-tile epilogue reads from memory
+  uint2 bias4[4];              // MFMA side: this lane's 4 output columns of each of the 4 column fragments
+  uint4 res8[16];              // row-major side: the residual of row step u (8 columns)
+  uint4 gate_lo, gate_hi;      // the two candidate per-frame gate rows
+  int f_lo;
+};
+// The bias FIRST: loads return in order and the staging needs nothing but the bias -- issued behind the 16 residual loads (round 4)
+// its `s_waitcnt` was a vmcnt(0) that held the whole staging back for an HBM round trip of the residual (seen in the ISA).
 template <int EPI>
-MMPL_DEV void gemm_epilogue_staged(const GemmArgs& g, const f32x4 (&acc)[2][4][4], char* stg, int mw, int nw, int lane) {
+MMPL_DEV void epi_load_bias(const GemmArgs& g, EpiIn& in, int nw, int lane) {
+  const int fchunk = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int nb = nw + 16 * j + 4 * fchunk;
+    in.bias4[j] = (g.bias && nb < g.N) ? *reinterpret_cast<const uint2*>(g.bias + nb) : uint2{0u, 0u};
+  }
+  asm volatile("" ::"v"(in.bias4[0].x), "v"(in.bias4[1].x), "v"(in.bias4[2].x), "v"(in.bias4[3].x));   // (keeps hipcc from sinking them behind the residual loads)
+}
+// Every residual load of the sub-tile is issued before its first store (the residual usually IS the output buffer) and all of them
+// are in flight at once.  The gate is a per-FRAME vector: the sub-tile's 128 rows touch at most two frames (rows_per_frame >= 128 on this
+// path, launcher), so its two candidate rows are fetched once, beside the residual, instead of one dependent L2 round trip per row step.
+template <int EPI, int U0 = 0, int U1 = 16>       // row steps [U0, U1) of the residual; the gate rows come with U0 == 0
+MMPL_DEV void epi_load_res(const GemmArgs& g, EpiIn& in, int mw, int nw, int lane) {
   constexpr bool HAS_RES = EPI == EPI_GATE_RES || EPI == EPI_RES;
-  const int frow = lane & 15, fchunk = lane >> 4;
   const int erow = lane >> 3, ec = lane & 7, n = nw + 8 * ec;      // row-major side: step u -> row 8 u + erow, columns 8 ec .. + 7
   const bool n_ok = n < g.N;                                        // N % 8 == 0 on this path (launcher)
-  uint4 res8[16];
   if (HAS_RES) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = U0; u < U1; ++u) {
       const int m = mw + 8 * u + erow;
       if (n_ok && m < g.M) {
         const u32x4* rp = reinterpret_cast<const u32x4*>(g.res + (size_t)m * g.ldres + n);
         const u32x4 rv = GEMM6_RESLD ? __builtin_nontemporal_load(rp) : *rp;
-        res8[u] = uint4{rv[0], rv[1], rv[2], rv[3]};
+        in.res8[u] = uint4{rv[0], rv[1], rv[2], rv[3]};
       } else {
-        res8[u] = uint4{0u, 0u, 0u, 0u};
+        in.res8[u] = uint4{0u, 0u, 0u, 0u};
       }
     }
   }
-  // the gate is a per-FRAME vector: the sub-tile's 128 rows touch at most two frames (rows_per_frame >= 128 on this path, launcher),
-  // so its two candidate rows are fetched once, beside the residual, instead of one dependent L2 round trip per row step
-  uint4 gate_lo = uint4{0u, 0u, 0u, 0u}, gate_hi = gate_lo;
-  int f_lo = 0;
+  if (U0 != 0) return;
+  in.gate_lo = uint4{0u, 0u, 0u, 0u};
+  in.gate_hi = in.gate_lo;
+  in.f_lo = 0;
   if (EPI == EPI_GATE_RES && n_ok) {
-    f_lo = min(mw, g.M - 1) / g.rows_per_frame;
+    in.f_lo = min(mw, g.M - 1) / g.rows_per_frame;
     const int f_hi = min(mw + 127, g.M - 1) / g.rows_per_frame;
-    gate_lo = *reinterpret_cast<const uint4*>(g.gate + (size_t)f_lo * g.gate_frame_stride + n);
-    gate_hi = *reinterpret_cast<const uint4*>(g.gate + (size_t)f_hi * g.gate_frame_stride + n);
+    in.gate_lo = *reinterpret_cast<const uint4*>(g.gate + (size_t)in.f_lo * g.gate_frame_stride + n);
+    in.gate_hi = *reinterpret_cast<const uint4*>(g.gate + (size_t)f_hi * g.gate_frame_stride + n);
   }
-  uint2 bias4[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int nb = nw + 16 * j + 4 * fchunk;
-    bias4[j] = (g.bias && nb < g.N) ? *reinterpret_cast<const uint2*>(g.bias + nb) : uint2{0u, 0u};
-  }
+}
+// MFMA side: bias, the Linear's bf16 rounding and the activation, the sub-tile into its 16 KiB of the idle ring (16-byte chunk c of row r
+// at r * 128 + 16 (c ^ (r & 7))), then the wave-level fence that lets the row-major side read it back
+template <int EPI>
+MMPL_DEV void epi_stage(const f32x4 (&acc)[2][4][4], const EpiIn& in, char* stg, int lane) {
+  const int frow = lane & 15, fchunk = lane >> 4;
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -461,8 +480,8 @@ MMPL_DEV void gemm_epilogue_staged(const GemmArgs& g, const f32x4 (&acc)[2][4][4
       const int row = 64 * h + 16 * i + frow;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float b[4] = {__uint_as_float(bias4[j].x << 16), __uint_as_float(bias4[j].x & 0xffff0000u),
-                            __uint_as_float(bias4[j].y << 16), __uint_as_float(bias4[j].y & 0xffff0000u)};
+        const float b[4] = {__uint_as_float(in.bias4[j].x << 16), __uint_as_float(in.bias4[j].x & 0xffff0000u),
+                            __uint_as_float(in.bias4[j].y << 16), __uint_as_float(in.bias4[j].y & 0xffff0000u)};
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -477,6 +496,13 @@ MMPL_DEV void gemm_epilogue_staged(const GemmArgs& g, const f32x4 (&acc)[2][4][4
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// Row-major side: a lane owns 8 consecutive columns of a row -> 16-byte residual / gate operands and stores, 128 contiguous bytes per row
+template <int EPI>
+MMPL_DEV void epi_finish(const GemmArgs& g, const EpiIn& in, const char* stg, int mw, int nw, int lane) {
+  constexpr bool HAS_RES = EPI == EPI_GATE_RES || EPI == EPI_RES;
+  const int erow = lane >> 3, ec = lane & 7, n = nw + 8 * ec;
+  const bool n_ok = n < g.N;
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
     const int row = 8 * u + erow, m = mw + row;
@@ -485,8 +511,8 @@ MMPL_DEV void gemm_epilogue_staged(const GemmArgs& g, const f32x4 (&acc)[2][4][4
     uint4 ov = yv;
     if (HAS_RES) {
       uint4 ev = uint4{0u, 0u, 0u, 0u};
-      if (EPI == EPI_GATE_RES) ev = (m / g.rows_per_frame == f_lo) ? gate_lo : gate_hi;
-      const uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w}, xw[4] = {res8[u].x, res8[u].y, res8[u].z, res8[u].w}, ew[4] = {ev.x, ev.y, ev.z, ev.w};
+      if (EPI == EPI_GATE_RES) ev = (m / g.rows_per_frame == in.f_lo) ? in.gate_lo : in.gate_hi;
+      const uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w}, xw[4] = {in.res8[u].x, in.res8[u].y, in.res8[u].z, in.res8[u].w}, ew[4] = {ev.x, ev.y, ev.z, ev.w};
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -505,6 +531,14 @@ MMPL_DEV void gemm_epilogue_staged(const GemmArgs& g, const f32x4 (&acc)[2][4][4
       store16_c(g.C + (size_t)m * g.ldc + n, ov);
     }
   }
+}
+template <int EPI>
+MMPL_DEV void gemm_epilogue_staged(const GemmArgs& g, const f32x4 (&acc)[2][4][4], char* stg, int mw, int nw, int lane) {
+  EpiIn in;
+  epi_load_bias<EPI>(g, in, nw, lane);
+  epi_load_res<EPI>(g, in, mw, nw, lane);
+  epi_stage<EPI>(acc, in, stg, lane);
+  epi_finish<EPI>(g, in, stg, mw, nw, lane);
 }
 
 // 16-byte system-scope accesses of the split-K partials: written through past the L2, read past L1 and L2 (valid between any two
@@ -1137,23 +1171,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     const int frow_e = lane_e & 15, fchunk_e = lane_e >> 4;
-    sfor<2>([&](auto nhi) {
+    const int mw = m0 + 128 * wm, nw0 = n0 + 128 * wn;
+    auto read_half = [](auto nhi, f32x4 (&acc)[2][4][4]) {
       constexpr int nh = decltype(nhi)::value;
-      f32x4 acc[2][4][4];
       sfor<128>([&acc](auto ii) {
         constexpr int x = decltype(ii)::value, i8 = x >> 4, j = (x >> 2) & 3, r = x & 3;
         float v;
         asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "i"(4 * (8 * i8 + 4 * nh + j) + r));
         acc[i8 >> 2][i8 & 3][j][r] = v;
       });
-      const int mw = m0 + 128 * wm, nw = n0 + 128 * wn + 64 * nh;
-      if (EPI != EPI_F32_SCALE && g.staged_epilogue) {
-        gemm_epilogue_staged<EPI>(g, acc, smem + wave * 32768 + nh * 16384, mw, nw, lane_e);
-      } else {
-        gemm_epilogue<EPI>(g, acc[0], mw, nw, frow_e, fchunk_e);
-        gemm_epilogue<EPI>(g, acc[1], mw + 64, nw, frow_e, fchunk_e);
+    };
+    if (EPI != EPI_F32_SCALE && g.staged_epilogue) {
+      // Round 5: the second half's bias / residual / gate loads are issued BEFORE the first half's read-back and stores (disjoint
+      // columns, so nothing it reads is about to be written), i.e. they fly under ~a third of the epilogue instead of stalling the
+      // second half's read-back for an HBM round trip.
+      char* stg0 = smem + wave * 32768;
+      EpiIn in0, in1;
+      epi_load_bias<EPI>(g, in0, nw0, lane_e);
+      epi_load_res<EPI>(g, in0, mw, nw0, lane_e);
+      {
+        f32x4 acc[2][4][4];
+        read_half(w64::ic<0>{}, acc);
+        epi_stage<EPI>(acc, in0, stg0, lane_e);
       }
-    });
+      epi_load_bias<EPI>(g, in1, nw0 + 64, lane_e);
+      // (the first NPRE row steps: the register file has no room for all 16 beside the second half's accumulators -- with more, hipcc
+      // spills or, worse, parks values in the accumulator file that still holds them: tests/test_isa_audit.py)
+      constexpr int NPRE = EPI == EPI_GATE_RES ? 0 : 8;
+      epi_load_res<EPI, 0, NPRE>(g, in1, mw, nw0 + 64, lane_e);
+      epi_finish<EPI>(g, in0, stg0, mw, nw0, lane_e);
+      {
+        f32x4 acc[2][4][4];
+        read_half(w64::ic<1>{}, acc);
+        epi_stage<EPI>(acc, in1, stg0 + 16384, lane_e);
+      }
+      epi_load_res<EPI, NPRE, 16>(g, in1, mw, nw0 + 64, lane_e);
+      epi_finish<EPI>(g, in1, stg0 + 16384, mw, nw0 + 64, lane_e);
+    } else {
+      sfor<2>([&](auto nhi) {
+        constexpr int nh = decltype(nhi)::value;
+        f32x4 acc[2][4][4];
+        read_half(nhi, acc);
+        gemm_epilogue<EPI>(g, acc[0], mw, nw0 + 64 * nh, frow_e, fchunk_e);
+        gemm_epilogue<EPI>(g, acc[1], mw + 64, nw0 + 64 * nh, frow_e, fchunk_e);
+      });
+    }
     if constexpr (GEMM6_TIMING) {      // per-wave { prologue, k loop, epilogue } shader cycles over the output (tools/bench_kernels.py gemmphases)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       tk3 = __builtin_readcyclecounter();

@@ -112,12 +112,13 @@ def assemble_chunk_seconds(step_seconds, first_step_index: int, stage_flops, ste
     return stage_s, float(steps_per_stage) * sum(stage_s)
 
 
-# Measured on MI355X (profiles/r05c_bench_concurrent_cfg_ab.log, r05d_*): with the two CFG branches of a denoise step captured as
-# PARALLEL branches of the step graph, the tails of one branch's kernels (partial last rounds of tiles, split-KV tails, launch gaps,
-# the chip-wide prologue / epilogue phases of short-K GEMMs) are filled by the other's.  Wan 1.3B at 480p (query rows x dim = 4.8 ...
-# 16.8 M): -5.6 ... -17 % per stage, -8.4 % per step; Wan 14B at 720p: the 2-frame stage (36.9 M) -1.3 %, the 6- and 7-frame
-# stages (111 ... 129 M) +0.6 ... +1.7 % (two long kernels contending for the same CUs and L2 lose more than their tails are worth).
-CONCURRENT_CFG_MAX_ROWS_X_DIM = 48e6
+# Measured on MI355X (profiles/r05c_bench_concurrent_cfg_ab.log, r05d_bench_concurrent_cfg_rule.log): with the two CFG branches of a
+# denoise step captured as PARALLEL branches of the step graph, the tails of one branch's kernels (partial last rounds of tiles,
+# split-KV tails, launch gaps, the chip-wide prologue / epilogue phases of short-K GEMMs) are filled by the other's.  By query rows x
+# model dim of the stage: Wan 1.3B at 480p (4.8 ... 16.8 M) -5.6 ... -17 % per stage, -8.4 ... -9.9 % per step; Wan 14B at 480p 16 M:
+# -12 %, 55.9 M: -1.7 %, 47.9 M: 0 ... -0.3 %; Wan 14B at 720p 36.9 M: -1.3 ... -2.4 %, 111 ... 129 M: -0.5 ... +2 % by box (two
+# chip-filling kernels contending for the same CUs and L2 lose about what their tails are worth).
+CONCURRENT_CFG_MAX_ROWS_X_DIM = 60e6
 
 
 def concurrent_cfg_pays(n_query_rows: int, dim: int) -> bool:

@@ -89,6 +89,32 @@ for step in "$@"; do
       grep -E "408 forwards|24 forwards|50 steps|i2v|redo counters|passed|failed|rc=|Error" $out/pipetests.log | tail -30 ;;
     chunk13)
       python tools/full_chunk.py --model 1.3B --res 480p > $out/full_chunk_1p3B_480p.json 2>> $out/bench.err; tail -c 500 $out/full_chunk_1p3B_480p.json ;;
+    libab)       # two PREBUILT libraries (tools/build/libmmpl_hip_{prev,new}.so) in situ, alternating: 14B / 720p and 1.3B / 480p; then bit-identity of the GEMMs
+      for v in prev new prev new; do
+        cp tools/build/libmmpl_hip_$v.so mmpl_amd/lib/libmmpl_hip.so
+        python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae --profile-all > $out/ab_tmp.json 2>> $out/bench.err; line $out/ab_tmp.json "14B/720p lib=$v" >> $out/lib_ab.log
+        python bench.py --model 1.3B --res 480p --steps 16 --warmup 8 --no-cpu-baseline --no-vae > $out/ab_tmp.json 2>> $out/bench.err; line $out/ab_tmp.json "1.3B/480p lib=$v" >> $out/lib_ab.log
+        timeout 600 python tools/gemm_v8_check.py > $out/gemm_sha_$v.log 2>&1
+        BENCH_SHAPES=$BIG timeout 300 python tools/bench_kernels.py gemm --iters 5 2>&1 | grep "^gemm" | sed "s/^/lib=$v /" >> $out/lib_ab_gemm_standalone.log
+      done
+      cp tools/build/libmmpl_hip_new.so mmpl_amd/lib/libmmpl_hip.so
+      diff $out/gemm_sha_prev.log $out/gemm_sha_new.log > $out/gemm_sha.diff && echo "GEMM outputs of the two libraries: identical hashes on every line" | tee -a $out/lib_ab.log
+      cat $out/lib_ab.log $out/lib_ab_gemm_standalone.log ;;
+    profiles)    # rocprofv3 kernel stats + PMC passes over bench.py itself (tools/r03_profiles.sh), summaries -> gpurun_out/prof_<tag>/
+      bash tools/r03_profiles.sh $tag stats hbm busy > $out/profiles.log 2>&1; tail -6 $out/profiles.log ;;
+    chunk14)
+      python tools/full_chunk.py --model 14B --res 720p > $out/full_chunk_14B_720p.json 2>> $out/bench.err; tail -c 500 $out/full_chunk_14B_720p.json ;;
+    others)      # the other BASELINE / reported configurations
+      python bench.py --model 14B --res 480p --no-cpu-baseline > $out/bench_14B_480p.json 2>> $out/bench.err; line $out/bench_14B_480p.json "14B/480p"
+      python bench.py --model 14B --res 720p --mode i2v --i2v-model --no-cpu-baseline > $out/bench_i2v_model_type_14B_720p.json 2>> $out/bench.err; line $out/bench_i2v_model_type_14B_720p.json "I2V model type 14B/720p"
+      python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae --heavy-tail --heavy-tail-gain 3 > $out/bench_14B_720p_heavy_tail_x3.json 2>> $out/bench.err; line $out/bench_14B_720p_heavy_tail_x3.json "heavy tail x3"
+      python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae --heavy-tail > $out/bench_14B_720p_heavy_tail_x8.json 2>> $out/bench.err; line $out/bench_14B_720p_heavy_tail_x8.json "heavy tail x8"
+      python3 -c "
+import json
+for f in ('x3','x8'):
+    r=json.loads(open('$out/bench_14B_720p_heavy_tail_'+f+'.json').read().strip().splitlines()[-1]); print(f, 'blocks redone', r.get('attn_blocks_redone_fraction'), 'waves failed', r.get('attn_waves_failed_fraction'))" ;;
+    n2gloo)      # the DEFAULT N = 2 line (a measured wavefront) on one GPU over gloo: functional, Wan 1.3B at 480p
+      timeout 1500 python bench.py --gpus 2 --dist-backend gloo --model 1.3B --res 480p --wavefront-budget-s 240 > $out/bench_default_n2_gloo_1p3B_480p.json 2>> $out/bench.err; tail -c 1500 $out/bench_default_n2_gloo_1p3B_480p.json ;;
     *) echo "unknown step $step" ;;
   esac
   clean_cores
