@@ -89,6 +89,9 @@ def parse():
                          "workspace): the tail of one branch's kernels (partial last rounds, split tails, launch gaps) is filled by the other's.  "
                          "Default: per stage where it pays (mmpl_amd.stage_plan.concurrent_cfg_pays -- what the pipeline does)")
     ap.add_argument("--no-concurrent-cfg", action="store_true", help="never: the two forwards one after the other on one stream")
+    ap.add_argument("--no-share-block0", action="store_true",
+                    help="the uncond forward recomputes block 0's self-attention instead of taking x after it from the cond forward (the two "
+                         "branches run it on identical inputs; what the pipeline's sequential step graphs do; bit-identical either way)")
     ap.add_argument("--wavefront-chunks", type=int, default=0,
                     help="C > 0: instead of K rotating steps, run ONE video of C chunks through the real pipeline and the real dependency chain "
                          "(chunk c on lane c %% lanes, RCCL anchor hand-off after the anchor stage, VAE consumer transform) and report the MEASURED "
@@ -466,6 +469,11 @@ def main():
         ckv = eng.precompute_context(ctx)
         # (.., cross_rows): the padded tail of the text K / V is one repeated row from row `rows` on -- explicit data, the same
         # path CrossAttnCache takes in the pipeline
+        if i == 1:
+            # what the pipeline's caches satisfy by construction (every forward runs on both branches with the same latents and timestep):
+            # layer 0 holds the same K / V in both -- the precondition of sharing block 0's self-attention between the branches
+            kc[0].copy_(caches[0][0][0])
+            vc[0].copy_(caches[0][1][0])
         caches.append((kc, vc, ckv[0], ckv[1], ckv.rows))
     # per-stage state: latents, visible slots, scheduler
     vis_frames = [[0, 1], [0, 1, 2, 3, 10, 11, 12, 19, 20], list(range(13)) + ([] if args.mode == "t2v" else [19, 20]),
@@ -583,6 +591,7 @@ def main():
             g = torch.cuda.CUDAGraph()
             from mmpl_amd.stage_plan import concurrent_cfg_pays
             st["concurrent"] = (args.concurrent_cfg or concurrent_cfg_pays(len(st["frames"]) * S, eng.dim)) and not args.no_concurrent_cfg
+            st["share"] = eng.shared_block0_buffer(len(st["frames"])) if (not st["concurrent"] and not args.no_share_block0) else None
             if st["concurrent"] and "ws2" not in st:
                 st["ws2"] = eng.second_workspace(len(st["frames"]))
                 st["side"] = torch.cuda.Stream(device=dev)
@@ -601,7 +610,8 @@ def main():
                 else:
                     for which, out in ((0, st["fc"]), (1, st["fu"])):
                         kc, vc, ck, cv, crows = caches[which]
-                        eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out, cross_rows=crows)
+                        eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out, cross_rows=crows,
+                                    share_out=st["share"] if which == 0 else None, share_in=st["share"] if which == 1 else None)
                 sched.step_cfg_table(st["fc"], st["fu"], st["lat"], st["t"])
             st["graph"], st["replays"] = g, 0
     concurrent_stages = [i for i, st in enumerate(stage_state) if st.get("concurrent")]
@@ -726,6 +736,7 @@ def main():
                        "frame_seqlen": S, "latent_hw": [lat_h, lat_w], "sampling_steps": 50, "guidance_scale": 5.0,
                        "timed_path": ("one hipGraph replay per denoise step (2 DiT forwards" +
                                       (f", as two parallel graph branches in stages {concurrent_stages}" if concurrent_stages else "") +
+                                      ("" if args.no_share_block0 else "; block 0's self-attention computed once per step where the branches run back to back") +
                                       " + fused CFG/UniPC, device-resident step tables)"
                                       if use_graph else ("one hipGraph replay per forward + host-issued flow exchange + fused CFG/UniPC launch"
                                                          if pair is not None and not args.eager else "eager launches")),
@@ -761,7 +772,7 @@ def main():
             traffic, traffic_src = None, None
             if args.model == "14B" and args.res == "720p" and args.mode == "t2v" and not args.heavy_tail:
                 # Fabric bytes per op cannot be collected inside this process (rocprofv3 --pmc wraps the program): the committed PMC
-                # passes over THIS command (tools/r04_profiles.sh: bench.py under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+                # passes over THIS command (tools/r03_profiles.sh: bench.py under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
                 # passes, mean over the rotation's self-attention ops).  The file is named explicitly by profiles/PMC_TRAFFIC.json,
                 # written by the collection script -- not picked by a sorted glob.
                 idx = os.path.join(ROOT, "profiles", "PMC_TRAFFIC.json")

@@ -84,11 +84,19 @@ int mmpl_dit_set_attn_stats(MmplDit* h, void* stats_dev);
  *                of row cross_rows -- the `distinct_rows` mmpl_dit_precompute_context reported for these contents.  The text
  *                cross-attention then attends over rows 0 .. cross_rows with the last one weighted text_len - cross_rows times:
  *                the same softmax, (text_len - cross_rows - 1) fewer keys.  text_len (or any value outside [0, text_len - 2])
- *                = attend over all text_len rows, which is always correct. */
+ *                = attend over all text_len rows, which is always correct.
+ *   share_out / share_in (both may be NULL, at most one non-NULL): dev [n_frames * S, dim] bf16.  Block 0's self-attention sees
+ *                nothing that differs between the two branches of classifier-free guidance (same latents, same timestep, and -- by
+ *                induction -- the same layer-0 K / V in both caches), only the text context differs and that enters after it.
+ *                share_out: this forward also leaves x as it is after block 0's self-attention residual there.  share_in: the
+ *                caller's statement that ANOTHER forward on the same x_in / t / frame_ids / write_slots / visible_slots, whose
+ *                layer-0 cache contents equal this one's, produced it: block 0's attention and output projection are skipped and
+ *                x continues from share_in (this forward's own layer-0 K / V slots are still written).  Same kernels on the same
+ *                inputs: the result is bit-identical to computing it. */
 int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int n_frames, const int* frame_ids,
                      const int* write_slots, const int* visible_slots, int n_visible, void* k_cache, void* v_cache,
-                     int n_slots, const void* cross_k, const void* cross_v, int cross_rows, void* out, void* workspace,
-                     size_t workspace_bytes, mmpl_stream_t stream);
+                     int n_slots, const void* cross_k, const void* cross_v, int cross_rows, void* share_out, const void* share_in,
+                     void* out, void* workspace, size_t workspace_bytes, mmpl_stream_t stream);
 
 /* attention() seam (wan/modules/attention.py:139-185) over paged K/V.  q/o: row r, head h at base + r*ld + h*128.
  * k_pages/v_pages: host arrays of n_pages dev pointers, each page = page_rows rows of stride ldk/ldv.

@@ -71,7 +71,7 @@ def load() -> C.CDLL:
     lib.mmpl_dit_context_workspace_bytes.restype = sz
     lib.mmpl_dit_precompute_context.argtypes = [vp, vp, vp, vp, vp, sz, C.POINTER(ci), vp]
     lib.mmpl_dit_forward.argtypes = [vp, vp, vp, ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), ci, vp, vp, ci, vp, vp,
-                                     ci, vp, vp, sz, vp]
+                                     ci, vp, vp, vp, vp, sz, vp]
     lib.mmpl_attn_fwd.argtypes = [vp, ci, vp, ci, C.POINTER(vp), C.POINTER(vp), ci, ci, ci, ci, ci, ci, cf, vp]
     lib.mmpl_attn_fwd_ws.argtypes = [vp, ci, vp, ci, C.POINTER(vp), C.POINTER(vp), ci, ci, ci, ci, ci, ci, cf, vp, sz, vp]
     lib.mmpl_attn_fwd_variant.argtypes = [vp, ci, vp, ci, C.POINTER(vp), C.POINTER(vp), ci, ci, ci, ci, ci, ci, cf, vp, sz, ci, ci, vp]

@@ -331,8 +331,8 @@ int mmpl_dit_set_attn_stats(MmplDit* h, void* stats_dev) {
 
 int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, const int* frame_ids,
                      const int* write_slots, const int* visible_slots, int n_visible, void* k_cache, void* v_cache,
-                     int n_slots, const void* cross_k, const void* cross_v, int cross_rows, void* out, void* workspace,
-                     size_t workspace_bytes, mmpl_stream_t stream) {
+                     int n_slots, const void* cross_k, const void* cross_v, int cross_rows, void* share_out, const void* share_in,
+                     void* out, void* workspace, size_t workspace_bytes, mmpl_stream_t stream) {
   if (!h || h->w.empty()) return fail("mmpl_dit_forward", "weights not bound");
   const MmplDitConfig& c = h->cfg;
   if (nF < 1 || nF > c.max_frames) return fail("mmpl_dit_forward", "n_frames out of range");
@@ -342,6 +342,7 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
     if (write_slots[i] >= 0) ++n_write;
   }
   if (n_write != 0 && n_write != nF) return fail("mmpl_dit_forward", "write_slots must be all >= 0 or all -1");
+  if (share_out && share_in) return fail("mmpl_dit_forward", "share_out and share_in are exclusive (producer or consumer of block 0's self-attention)");
   const bool persist = n_write == nF;
   const int n_pages = n_visible + (persist ? 0 : nF);
   if (n_pages < 1 || n_pages > MMPL_MAX_PAGES) return fail("mmpl_dit_forward", "too many / no visible KV pages");
@@ -379,63 +380,76 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
     const bf16_t* em = w.emod + (size_t)l * nF * 6 * d;  // [nF][6][d]
     bf16_t* kc = (bf16_t*)k_cache + (size_t)l * layer_stride;
     bf16_t* vc = (bf16_t*)v_cache + (size_t)l * layer_stride;
-    // -- self attention (causal_fps_model.py:342-348)
-    {
-      LnArgs a{w.x, d, w.xn, d, Lq, d, c.eps, em + 1 * d, em + 0 * d, 6 * d, S, nullptr, nullptr};
-      ProfScope ps(K_LAYERNORM, 0, s);
-      HIP_TRY(mmpl_launch_layernorm(a, s), "norm1");
-    }
-    {
-      // fused q|k|v projection; the V third goes straight into its KV-cache pages (V is cached unchanged,
-      // causal_fps_model.py:217), so the norm / RoPE pass below only touches q and k
-      GemmArgs g{w.xn, d, h->Lw(l, L_QKV_W), d, h->Lw(l, L_QKV_B), w.big, 3 * d, Lq, 3 * d, d, EPI_BIAS_VPAGES, nullptr, 0, nullptr, 0, S,
-                 1.0f, 0, 0, 0, 0, 0};
-      for (int i = 0; i < nF; ++i) g.v_dst[i] = persist ? vc + (size_t)write_slots[i] * S * d : w.vsc + (size_t)i * S * d;
-      g.v_col0 = 2 * d;
-      g.v_ld = d;
-      g.tile_counter = tc;
-      g.splitk_ws = w.splitk; g.splitk_cnt = tc + 64;
-      ProfScope ps(K_GEMM, 2.0 * Lq * 3.0 * d * d, s);
-      HIP_TRY(mmpl_launch_gemm(g, s), "qkv gemm");
-    }
-    {
-      QkNormArgs a = {};
-      a.q = w.big; a.ldq = 3 * d; a.k = w.big + d; a.ldk = 3 * d; a.v = nullptr; a.ldv = 3 * d;
-      a.wq = h->Lw(l, L_NQ); a.wk = h->Lw(l, L_NK); a.rows = Lq; a.d = d; a.eps = c.eps; a.rope = 1;
-      a.q_scale = prescale_q ? scale * 1.4426950408889634f : 0.f;
-      a.cos_tab = h->cos_tab; a.sin_tab = h->sin_tab; a.rows_per_frame = S; a.grid_w = h->gw;
-      for (int i = 0; i < nF; ++i) {
-        a.frame_ids[i] = frame_ids[i];
-        a.k_dst[i] = persist ? kc + (size_t)write_slots[i] * S * d : w.ksc + (size_t)i * S * d;
-        a.v_dst[i] = persist ? vc + (size_t)write_slots[i] * S * d : w.vsc + (size_t)i * S * d;
+    // Block 0's self-attention depends on nothing but the latents, the timestep and the cache contents -- none of which differ
+    // between the two branches of classifier-free guidance.  share_in: the caller states exactly that for this forward and hands in
+    // x as the OTHER branch's forward (share_out) left it after block 0's self-attention residual: the attention and its output
+    // projection are skipped (this branch's own K / V slots are still written when the stage persists them).  Same kernels, same
+    // inputs -> the bits the skipped launches would have produced.
+    const bool take_shared = l == 0 && share_in != nullptr;
+    if (!take_shared || persist) {
+      // -- self attention (causal_fps_model.py:342-348)
+      {
+        LnArgs a{w.x, d, w.xn, d, Lq, d, c.eps, em + 1 * d, em + 0 * d, 6 * d, S, nullptr, nullptr};
+        ProfScope ps(K_LAYERNORM, 0, s);
+        HIP_TRY(mmpl_launch_layernorm(a, s), "norm1");
       }
-      ProfScope ps(K_QKNORM, 0, s);
-      HIP_TRY(mmpl_launch_qknorm(a, s), "qk norm + rope + kv write");
-    }
-    {
-      AttnArgs a = {};
-      a.q = w.big; a.ldq = 3 * d; a.o = w.attn; a.ldo = d; a.ldk = d; a.ldv = d; a.page_rows = S; a.Lq = Lq; a.H = H; a.scale = scale;
-      int np = 0;
-      for (int i = 0; i < n_visible; ++i, ++np) {
-        a.k_pages[np] = kc + (size_t)visible_slots[i] * S * d;
-        a.v_pages[np] = vc + (size_t)visible_slots[i] * S * d;
+      {
+        // fused q|k|v projection; the V third goes straight into its KV-cache pages (V is cached unchanged,
+        // causal_fps_model.py:217), so the norm / RoPE pass below only touches q and k
+        GemmArgs g{w.xn, d, h->Lw(l, L_QKV_W), d, h->Lw(l, L_QKV_B), w.big, 3 * d, Lq, 3 * d, d, EPI_BIAS_VPAGES, nullptr, 0, nullptr, 0, S,
+                   1.0f, 0, 0, 0, 0, 0};
+        for (int i = 0; i < nF; ++i) g.v_dst[i] = persist ? vc + (size_t)write_slots[i] * S * d : w.vsc + (size_t)i * S * d;
+        g.v_col0 = 2 * d;
+        g.v_ld = d;
+        g.tile_counter = tc;
+        g.splitk_ws = w.splitk; g.splitk_cnt = tc + 64;
+        ProfScope ps(K_GEMM, 2.0 * Lq * 3.0 * d * d, s);
+        HIP_TRY(mmpl_launch_gemm(g, s), "qkv gemm");
       }
-      if (!persist)
-        for (int i = 0; i < nF; ++i, ++np) {
-          a.k_pages[np] = w.ksc + (size_t)i * S * d;
-          a.v_pages[np] = w.vsc + (size_t)i * S * d;
-          a.page_group[np] = 1;                      // the workspace, not the cache allocation (order independent of their addresses)
+      {
+        QkNormArgs a = {};
+        a.q = w.big; a.ldq = 3 * d; a.k = w.big + d; a.ldk = 3 * d; a.v = nullptr; a.ldv = 3 * d;
+        a.wq = h->Lw(l, L_NQ); a.wk = h->Lw(l, L_NK); a.rows = Lq; a.d = d; a.eps = c.eps; a.rope = 1;
+        a.q_scale = prescale_q ? scale * 1.4426950408889634f : 0.f;
+        a.cos_tab = h->cos_tab; a.sin_tab = h->sin_tab; a.rows_per_frame = S; a.grid_w = h->gw;
+        for (int i = 0; i < nF; ++i) {
+          a.frame_ids[i] = frame_ids[i];
+          a.k_dst[i] = persist ? kc + (size_t)write_slots[i] * S * d : w.ksc + (size_t)i * S * d;
+          a.v_dst[i] = persist ? vc + (size_t)write_slots[i] * S * d : w.vsc + (size_t)i * S * d;
         }
-      a.n_pages = np;
-      a.variant = self_variant;
-      a.q_prescaled = prescale_q;
-      a.split_ws = (float*)w.xn;                    // norm1's output is dead once the QKV GEMM has consumed it
-      a.split_ws_bytes = (size_t)Lq * d * sizeof(bf16_t);
-      a.redo_stats = h->attn_stats;
-      ProfScope ps(K_ATTN_SELF, 4.0 * Lq * (double)np * S * d, s);
-      HIP_TRY(mmpl_launch_attention(a, s), "self attention");
+        ProfScope ps(K_QKNORM, 0, s);
+        HIP_TRY(mmpl_launch_qknorm(a, s), "qk norm + rope + kv write");
+      }
     }
-    TRY(gemm(w.attn, d, h->Lw(l, L_O_W), d, h->Lw(l, L_O_B), w.x, d, Lq, d, d, EPI_GATE_RES, w.x, d, em + 2 * d, 6 * d, S, s, tc, w.splitk));
+    if (take_shared) {
+      HIP_TRY(hipMemcpyAsync(w.x, share_in, (size_t)Lq * d * sizeof(bf16_t), hipMemcpyDeviceToDevice, s), "shared block-0 x");
+    } else {
+    {
+        AttnArgs a = {};
+        a.q = w.big; a.ldq = 3 * d; a.o = w.attn; a.ldo = d; a.ldk = d; a.ldv = d; a.page_rows = S; a.Lq = Lq; a.H = H; a.scale = scale;
+        int np = 0;
+        for (int i = 0; i < n_visible; ++i, ++np) {
+          a.k_pages[np] = kc + (size_t)visible_slots[i] * S * d;
+          a.v_pages[np] = vc + (size_t)visible_slots[i] * S * d;
+        }
+        if (!persist)
+          for (int i = 0; i < nF; ++i, ++np) {
+            a.k_pages[np] = w.ksc + (size_t)i * S * d;
+            a.v_pages[np] = w.vsc + (size_t)i * S * d;
+            a.page_group[np] = 1;                      // the workspace, not the cache allocation (order independent of their addresses)
+          }
+        a.n_pages = np;
+        a.variant = self_variant;
+        a.q_prescaled = prescale_q;
+        a.split_ws = (float*)w.xn;                    // norm1's output is dead once the QKV GEMM has consumed it
+        a.split_ws_bytes = (size_t)Lq * d * sizeof(bf16_t);
+        a.redo_stats = h->attn_stats;
+        ProfScope ps(K_ATTN_SELF, 4.0 * Lq * (double)np * S * d, s);
+        HIP_TRY(mmpl_launch_attention(a, s), "self attention");
+      }
+      TRY(gemm(w.attn, d, h->Lw(l, L_O_W), d, h->Lw(l, L_O_B), w.x, d, Lq, d, d, EPI_GATE_RES, w.x, d, em + 2 * d, 6 * d, S, s, tc, w.splitk));
+      if (l == 0 && share_out) HIP_TRY(hipMemcpyAsync(share_out, w.x, (size_t)Lq * d * sizeof(bf16_t), hipMemcpyDeviceToDevice, s), "share block-0 x");
+    }
     // -- cross attention (causal_fps_model.py:352-353, model.py:161-194)
     {
       LnArgs a{w.x, d, w.xn, d, Lq, d, c.eps, nullptr, nullptr, 0, S, h->Lw(l, L_N3_W), h->Lw(l, L_N3_B)};

@@ -64,6 +64,7 @@ class DitEngine:
         self._weights: List[torch.Tensor] = []
         self._ws: Dict[int, torch.Tensor] = {}
         self._ws2: Optional[torch.Tensor] = None
+        self._share: Optional[torch.Tensor] = None
         self._ctx_ws: Optional[torch.Tensor] = None
         self._i2v_w: Optional[dict] = None                 # img_emb + per-layer k_img / v_img / norm_k_img (model_type 'i2v')
         self._img_kv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
@@ -218,6 +219,14 @@ class DitEngine:
                 self._ws[n_frames] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._ws[n_frames]
 
+    def shared_block0_buffer(self, n_frames: int) -> torch.Tensor:
+        """[n_frames * S, dim] bf16: x after block 0's self-attention residual, handed from the cond forward of a denoise step
+        (`share_out`) to the uncond one (`share_in`).  One buffer, sized for the largest stage seen so far."""
+        n = n_frames * self.S * self.dim
+        if self._share is None or self._share.numel() < n:
+            self._share = torch.empty(n, dtype=torch.bfloat16, device=self.device)
+        return self._share
+
     def second_workspace(self, n_frames: int) -> torch.Tensor:
         """A private scratch buffer for a forward that runs CONCURRENTLY with another one of this engine (the uncond branch of a
         denoise step on a second stream): one buffer, sized for the largest stage seen so far, allocated outside any capture."""
@@ -230,11 +239,15 @@ class DitEngine:
     def forward(self, x: torch.Tensor, t: torch.Tensor, frame_ids: Sequence[int], write_slots: Sequence[int],
                 visible_slots: Sequence[int], k_cache: torch.Tensor, v_cache: torch.Tensor, cross_k: torch.Tensor,
                 cross_v: torch.Tensor, out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
-                cross_rows: Optional[int] = None) -> torch.Tensor:
+                cross_rows: Optional[int] = None, share_out: Optional[torch.Tensor] = None,
+                share_in: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x: [nF, in_dim, lat_h, lat_w] bf16 (i2v: x and y concatenated on the channel axis); t: [nF] float32 (device).
         Returns the flow prediction [nF, 16, lat_h, lat_w].
         `cross_rows`: the `CrossKV.rows` that belongs to the CONTENTS of cross_k / cross_v (rows cross_rows .. text_len-1 repeat one
         row): the text cross-attention then runs over cross_rows + 1 keys.  None = attend over all text_len rows.
+        `share_out` / `share_in` ([nF * S, dim] bf16, see `shared_block0_buffer`): the two branches of classifier-free guidance run
+        block 0's self-attention on identical inputs; the first forward leaves x after that residual in `share_out`, the second
+        takes it as `share_in` and skips the attention and its output projection (include/mmpl_hip.h; bit-identical).
         `workspace`: a private scratch buffer (>= workspace_bytes(nF)) for a forward that runs concurrently with another
         one on a different stream (cond / uncond); default: the engine's own."""
         nF = x.shape[0]
@@ -242,6 +255,8 @@ class DitEngine:
         assert t.dtype == torch.float32 and t.numel() == nF and t.is_cuda
         if self.model_type == "i2v" and self._img_kv is None:
             raise RuntimeError("DitEngine: an i2v model needs set_image_kv(*precompute_image_context(clip_fea)) before forward")
+        for sh in (share_out, share_in):
+            assert sh is None or (sh.dtype == torch.bfloat16 and sh.is_contiguous() and sh.numel() >= nF * self.S * self.dim and sh.device == x.device)
         if out is None:
             out = torch.empty(nF, 16, self.lat_h, self.lat_w, dtype=torch.bfloat16, device=x.device)
         ws = self.workspace(nF) if workspace is None else workspace
@@ -251,8 +266,9 @@ class DitEngine:
             _lib.check(self._lib.mmpl_dit_forward(
                 self._h, _lib.ptr(x), _lib.ptr(t), nF, ia(frame_ids), ia(write_slots), ia(visible_slots), len(visible_slots),
                 _lib.ptr(k_cache), _lib.ptr(v_cache), n_slots, _lib.ptr(cross_k), _lib.ptr(cross_v),
-                self.text_len if cross_rows is None else int(cross_rows), _lib.ptr(out), _lib.ptr(ws),
-                ws.numel(), _lib.stream_ptr()), "mmpl_dit_forward")
+                self.text_len if cross_rows is None else int(cross_rows),
+                None if share_out is None else _lib.ptr(share_out), None if share_in is None else _lib.ptr(share_in),
+                _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "mmpl_dit_forward")
         return out
 
     # ------------------------------------------------------------------ hipGraph

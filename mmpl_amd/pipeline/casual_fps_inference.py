@@ -74,6 +74,11 @@ class CausalFPSInferencePipeline(torch.nn.Module):
         # Same kernels, same arguments, same bits either way (tests/test_pipeline_gpu.py).
         self.concurrent_cfg: Optional[bool] = None
         self._side_stream = None
+        # Block 0's self-attention is the same computation in both CFG branches (same latents, same timestep, the same layer-0 K / V
+        # in both caches: every forward this pipeline issues runs on both branches); in the sequential step graphs the uncond forward
+        # takes x after that residual from the cond forward instead of recomputing it (mmpl_dit_forward share_out / share_in;
+        # bit-identical).  False switches it off.
+        self.share_block0 = True
         self.cfg_pair = None              # mmpl_amd.handoff.CfgPair: this rank runs only the cond (role 0) / uncond (role 1) branch
 
         # ---- "add new noise on previous frames" schedule (casual_fps_inference.py:93-108); the randint keeps the
@@ -87,11 +92,12 @@ class CausalFPSInferencePipeline(torch.nn.Module):
         return self
 
     # ------------------------------------------------------------------------------------------------------------
-    def _forward(self, latents, cond, timestep, kv, cross, frames, out=None, workspace=None):
+    def _forward(self, latents, cond, timestep, kv, cross, frames, out=None, workspace=None, share_out=None, share_in=None):
         S = self.frame_seq_length
         starts = [f * S for f in frames]
         return self.generator_cond(noisy_image_or_video=latents, conditional_dict=cond, timestep=timestep, kv_cache=kv,
-                                   crossattn_cache=cross, current_start=starts, cache_start=starts, out=out, workspace=workspace)[0]
+                                   crossattn_cache=cross, current_start=starts, cache_start=starts, out=out, workspace=workspace,
+                                   share_out=share_out, share_in=share_in)[0]
 
     def _branches(self, cond, uncond):
         """[(conditional_dict, kv_cache, crossattn_cache, index into the flow pair)] this rank computes."""
@@ -223,6 +229,7 @@ class CausalFPSInferencePipeline(torch.nn.Module):
                             from ..stage_plan import concurrent_cfg_pays
                             concurrent = concurrent_cfg_pays(len(frames) * S, engine.dim)
                         ws2 = None
+                        share = engine.shared_block0_buffer(len(frames)) if (self.share_block0 and not concurrent) else None
                         if concurrent:                                      # (allocations and the stream: outside the capture)
                             ws2 = engine.second_workspace(len(frames))
                             if self._side_stream is None:
@@ -239,8 +246,9 @@ class CausalFPSInferencePipeline(torch.nn.Module):
                                     self._forward(latents, d1, timestep, kv1, cr1, frames, outs[1], workspace=ws2)
                                 main.wait_stream(side)                          # join: the CFG / UniPC update needs both
                             else:
-                                for (d, kv, cross, _), o in zip(branches, outs):
-                                    self._forward(latents, d, timestep, kv, cross, frames, o)
+                                for bi, ((d, kv, cross, _), o) in enumerate(zip(branches, outs)):
+                                    self._forward(latents, d, timestep, kv, cross, frames, o, share_out=share if bi == 0 else None,
+                                                  share_in=share if bi == 1 else None)
                             sample_scheduler.step_cfg_table(flow[0], flow[1], latents, timestep)
                 if step_graph is not None:
                     timestep.fill_(float(sample_scheduler.timesteps[0]))

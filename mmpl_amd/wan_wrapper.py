@@ -189,7 +189,8 @@ class WanFPSWrapper(torch.nn.Module):
                 kv_cache: Optional[KVCache] = None, crossattn_cache: Optional[CrossAttnCache] = None,
                 current_start=None, classify_mode=False, concat_time_embeddings=False, clean_x=None, aug_t=None,
                 cache_start=None, out: Optional[torch.Tensor] = None, return_x0: bool = False, clip_fea=None, y=None,
-                workspace: Optional[torch.Tensor] = None):
+                workspace: Optional[torch.Tensor] = None, share_out: Optional[torch.Tensor] = None,
+                share_in: Optional[torch.Tensor] = None):
         assert kv_cache is not None and crossattn_cache is not None, "the FPS path always runs with caches"
         assert noisy_image_or_video.shape[0] == 1, "batch size 1 (as every reference entry point)"
         S = self.engine.S
@@ -213,7 +214,8 @@ class WanFPSWrapper(torch.nn.Module):
         t = timestep.reshape(-1).to(device=x.device, dtype=torch.float32)
         flow = self.engine.forward(x, t, frames, StagePlan.write_slots(frames), [slot_of(o // S) for o in vis],
                                    kv_cache.k_all, kv_cache.v_all, crossattn_cache.k_all, crossattn_cache.v_all,
-                                   out=None if out is None else out[0], cross_rows=crossattn_cache.rows, workspace=workspace)
+                                   out=None if out is None else out[0], cross_rows=crossattn_cache.rows, workspace=workspace,
+                                   share_out=share_out, share_in=share_in)
         flow_pred = flow.unsqueeze(0)
         pred_x0 = None
         if return_x0:                                                     # wan_wrapper.py:373-397 (unused by the pipeline)

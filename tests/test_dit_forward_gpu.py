@@ -316,3 +316,48 @@ def test_attention_redo_counters_blocks_and_waves():
         assert eng.read_attn_stats() == (0, 0, 0)                     # off: later eager forwards do not count
     print("attention redo counters {gain: (blocks, blocks redone, waves with a failing row)}:", seen)
     assert seen[1.0][1] == 0 and seen[12.0][1] > 0
+
+
+@pytest.mark.parametrize("persist", [True, False])
+def test_shared_block0_self_attention_is_bit_identical(persist):
+    """mmpl_dit_forward share_out / share_in: block 0's self-attention sees nothing that differs between the two CFG branches (same
+    latents, same timestep, the same layer-0 K / V in both caches; the text context enters after it).  The cond forward leaves x
+    after that residual in `share_out`; the uncond forward given it as `share_in` skips block 0's attention and output projection.
+    Against the uncond forward computed in full: same flow, same cache contents (its own layer-0 K / V slots are still written),
+    bit for bit -- for a stage that persists its K / V and for the one that attends its own scratch pages."""
+    from mmpl_amd.dit import DitEngine
+    from mmpl_amd.synthetic import WAN_CONFIGS, dit_state_dict, philox_normal
+    cfg = WAN_CONFIGS["tiny"]
+    eng = DitEngine(cfg, 16, 24, "cuda:0")
+    eng.load_state_dict(dit_state_dict(cfg, seed=3))
+    frames = [4, 5, 6]
+    ws_slots = [4, 5, 6] if persist else [-1, -1, -1]
+    vis = [0, 1, 4, 5, 6] if persist else [0, 1, 2]
+    x = philox_normal([3, 16, 16, 24], 7).cuda()
+    t = torch.full([3], 433.0, dtype=torch.float32).cuda()
+    kv_c = eng.precompute_context(philox_normal([30, cfg["text_dim"]], 1).cuda())
+    kv_u = eng.precompute_context(philox_normal([9, cfg["text_dim"]], 2).cuda())
+
+    def caches(seed):
+        kc, vc = eng.new_kv_cache(15)
+        kc.copy_(philox_normal(list(kc.shape), seed).cuda())
+        vc.copy_(philox_normal(list(vc.shape), seed + 1).cuda())
+        return kc, vc
+    kc_c, vc_c = caches(10)
+    outs = {}
+    for mode in ("full", "shared"):
+        kc_u, vc_u = caches(20)
+        kc_u[0].copy_(kc_c[0])                      # the precondition: layer 0 of the two caches agrees (deeper layers and contexts do not)
+        vc_u[0].copy_(vc_c[0])
+        kc1, vc1 = kc_c.clone(), vc_c.clone()
+        share = eng.shared_block0_buffer(3) if mode == "shared" else None
+        yc = eng.forward(x, t, frames, ws_slots, vis, kc1, vc1, kv_c[0], kv_c[1], cross_rows=kv_c.rows, share_out=share).clone()
+        yu = eng.forward(x, t, frames, ws_slots, vis, kc_u, vc_u, kv_u[0], kv_u[1], cross_rows=kv_u.rows, share_in=share).clone()
+        torch.cuda.synchronize()
+        outs[mode] = (yc, yu, kc_u.clone(), vc_u.clone())
+    assert torch.equal(outs["full"][0], outs["shared"][0])                  # the producer's own result is untouched
+    assert torch.equal(outs["full"][1], outs["shared"][1]), rel_l2(outs["shared"][1], outs["full"][1])
+    assert torch.equal(outs["full"][2], outs["shared"][2]) and torch.equal(outs["full"][3], outs["shared"][3])
+    assert not torch.equal(outs["full"][0], outs["full"][1])                # (the branches do differ: another context)
+    with pytest.raises(RuntimeError, match="exclusive"):
+        eng.forward(x, t, frames, ws_slots, vis, kc_c, vc_c, kv_c[0], kv_c[1], share_out=eng.shared_block0_buffer(3), share_in=eng.shared_block0_buffer(3))

@@ -164,3 +164,10 @@ def test_concurrent_cfg_branches_are_bit_identical_to_sequential():
     assert pipe._side_stream is not None
     for mode in (True, None):
         assert torch.equal(res[mode][0], res[False][0]) and torch.equal(res[mode][1], res[False][1]), mode
+    # ... and the sequential step graphs with block 0's self-attention computed once per step (share_block0, the default) against
+    # both branches computing it: the same bits again
+    pipe.concurrent_cfg, pipe.share_block0 = False, False
+    _, a = pipe.inference(noise.cuda(), ["a cat"], return_latents=True, decode=False)
+    _, b = pipe.inference(noise.cuda(), ["a cat"], initial_latent=init.cuda(), return_latents=True, decode=False)
+    torch.cuda.synchronize()
+    assert torch.equal(a, res[False][0]) and torch.equal(b, res[False][1])

@@ -115,6 +115,11 @@ for f in ('x3','x8'):
     r=json.loads(open('$out/bench_14B_720p_heavy_tail_'+f+'.json').read().strip().splitlines()[-1]); print(f, 'blocks redone', r.get('attn_blocks_redone_fraction'), 'waves failed', r.get('attn_waves_failed_fraction'))" ;;
     n2gloo)      # the DEFAULT N = 2 line (a measured wavefront) on one GPU over gloo: functional, Wan 1.3B at 480p
       timeout 1500 python bench.py --gpus 2 --dist-backend gloo --model 1.3B --res 480p --wavefront-budget-s 240 > $out/bench_default_n2_gloo_1p3B_480p.json 2>> $out/bench.err; tail -c 1500 $out/bench_default_n2_gloo_1p3B_480p.json ;;
+    shareab)     # block 0's self-attention computed once per step (default) vs by both branches: 14B / 720p and 14B / 480p, alternating
+      for a in "--no-share-block0" "" "--no-share-block0" ""; do
+        python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae $a > $out/sh_tmp.json 2>> $out/bench.err; line $out/sh_tmp.json "14B/720p [$a]" >> $out/bench_share_block0_ab.log
+        python bench.py --res 480p --steps 8 --warmup 4 --no-cpu-baseline --no-vae $a > $out/sh_tmp.json 2>> $out/bench.err; line $out/sh_tmp.json "14B/480p [$a]" >> $out/bench_share_block0_ab.log
+      done; cat $out/bench_share_block0_ab.log ;;
     *) echo "unknown step $step" ;;
   esac
   clean_cores
