@@ -81,8 +81,8 @@ constexpr int AO = 0, AQ = 128, AV = 192;      // accumulator-file map
 // Timing ablations for tools/w64_sweep.sh (results are garbage): -DW64_ABL=<bits>  1 no LDS-DMA in the loop, 2 no softmax,
 // 4 no fragment reads, 8 no barrier / waits, 16 leave per-wave loop cycle counts in o (tools/attn_dev.py cycles), 32 / 64 / 128
 // no exp / row-sum adds / bf16 packs, 256 every V fragment by ONE ds_read_b128 in K's conflict-free lane pattern instead of two
-// ds_read_b64_tr_b16 (what a V tile stored pre-transposed would cost: same LDS bytes, half the V read instructions).  0 in every
-// shipped build.
+// ds_read_b64_tr_b16 (what a V tile stored pre-transposed would cost: same LDS bytes, half the V read instructions), 512 the FAST pass's
+// v_exp_f32 replaced by four plain VALU instructions (the floor of what a polynomial exp2 on the FMA units would issue).  0 in every shipped build.
 #ifndef W64_ABL
 #define W64_ABL 0
 #endif
@@ -289,7 +289,11 @@ struct Ctx {
   template <int MODE, int X, int Q, int EL> MMPL_DEV void sm_e() {
     if constexpr (W64_ABL & (2 | 32)) return;
     constexpr int h = Q >> 3, e = (Q & 7) * 2 + EL;
-    if constexpr (MODE == 0)
+    if constexpr (MODE == 0 && (W64_ABL & 512))
+      // timing mock of exp2 WITHOUT the transcendental unit (garbage values): the cheapest sequence a real one could be -- fract,
+      // a degree-2 polynomial (2 FMAs), the integer part back into the exponent (v_ldexp with a float -> int convert folded away)
+      asm volatile("v_fract_f32 %0, %1\n\tv_fma_f32 %0, %0, %0, %1\n\tv_fma_f32 %0, %0, %1, %0\n\tv_ldexp_f32 %0, %0, 1" : "=&v"(t[X][Q & 1][EL]) : "v"(S[X][h][e]));
+    else if constexpr (MODE == 0)
       asm volatile("v_exp_f32 %0, %1" : "=v"(t[X][Q & 1][EL]) : "v"(S[X][h][e]));
     else
       asm volatile("v_sub_f32 %0, %1, %2\n\tv_exp_f32 %0, %0" : "=&v"(t[X][Q & 1][EL]) : "v"(S[X][h][e]), "v"(mref[X]));
