@@ -70,3 +70,21 @@ def test_bench_chunk_time_assembly():
     prop = [f / 1e15 for f in fl]
     st, chunk = assemble_chunk_seconds(prop[:2], 0, fl)
     assert all(abs(a - b) < 1e-9 for a, b in zip(st, prop))
+
+
+def test_concurrent_cfg_rule():
+    """mmpl_amd.stage_plan.concurrent_cfg_pays: parallel CFG branches for the stages where it was measured to pay (query rows x dim <=
+    60 M: all of Wan 1.3B at 480p, 14B at 480p, the 2-frame stage of 14B at 720p), sequential for the long stages of 14B at 720p."""
+    from mmpl_amd.stage_plan import concurrent_cfg_pays as pays
+    assert all(pays(n * 1560, 1536) for n in (1, 2, 6, 7))                  # Wan 1.3B / 480p
+    assert all(pays(n * 1560, 5120) for n in (2, 6, 7))                     # Wan 14B / 480p
+    assert pays(2 * 3600, 5120) and not pays(6 * 3600, 5120) and not pays(7 * 3600, 5120)   # Wan 14B / 720p
+
+
+def test_cross_kv_is_a_pair_with_a_row_count():
+    import torch
+    from mmpl_amd.dit import CrossKV
+    k, v = torch.zeros(2, 3), torch.ones(2, 3)
+    kv = CrossKV(k, v, 48)
+    a, b = kv
+    assert a is k and b is v and kv.rows == 48 and len(kv) == 2 and kv[0] is k

@@ -129,6 +129,11 @@ for f in ('x3','x8'):
         echo "== M=$m MMPL_GEMM_GROUP=$g (0 = the launcher's choice)" >> $out/gemm_group_sweep.log
         MMPL_GEMM_GROUP=$g BENCH_SHAPES=$(echo $BIG | sed "s/25200/$m/g") timeout 300 python tools/bench_kernels.py gemm --iters 5 2>&1 | grep "^gemm" | sed 's/|  + split.*//' >> $out/gemm_group_sweep.log
       done; done; cat $out/gemm_group_sweep.log ;;
+    schedsweep)  # attention schedule generator settings (issue-slot budget per MFMA gap, DMA weight) with the polynomial exp2, in situ
+      for cfg in "10:4" "11:4" "12:4" "11:10" "9.5:3" "10:4"; do
+        W64_BUDGET=${cfg%%:*} W64_WDMA=${cfg##*:} python tools/gen_attn_w64.py > $out/gen.log 2>&1 || { echo "budget $cfg: does not fit" >> $out/attn_sched_sweep.log; continue; }
+        build ""; python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae > $out/ss_tmp.json 2>> $out/bench.err; line $out/ss_tmp.json "budget:wdma $cfg ($(tail -1 $out/gen.log))" >> $out/attn_sched_sweep.log
+      done; git checkout mmpl_amd/csrc/attn_w64_sched.inc 2>/dev/null || W64_BUDGET=10 W64_WDMA=4 python tools/gen_attn_w64.py > /dev/null; build ""; cat $out/attn_sched_sweep.log ;;
     *) echo "unknown step $step" ;;
   esac
   clean_cores
