@@ -81,8 +81,8 @@ constexpr int AO = 0, AQ = 128, AV = 192;      // accumulator-file map
 // Timing ablations for tools/w64_sweep.sh (results are garbage): -DW64_ABL=<bits>  1 no LDS-DMA in the loop, 2 no softmax,
 // 4 no fragment reads, 8 no barrier / waits, 16 leave per-wave loop cycle counts in o (tools/attn_dev.py cycles), 32 / 64 / 128
 // no exp / row-sum adds / bf16 packs, 256 every V fragment by ONE ds_read_b128 in K's conflict-free lane pattern instead of two
-// ds_read_b64_tr_b16 (what a V tile stored pre-transposed would cost: same LDS bytes, half the V read instructions), 512 the FAST pass's
-// v_exp_f32 replaced by four plain VALU instructions (the floor of what a polynomial exp2 on the FMA units would issue).  0 in every shipped build.
+// ds_read_b64_tr_b16 (what a V tile stored pre-transposed would cost: same LDS bytes, half the V read instructions).  0 in every
+// shipped build.
 #ifndef W64_ABL
 #define W64_ABL 0
 #endif
@@ -96,10 +96,8 @@ struct Ctx {
   bf16x8 kf[16];         // K fragments of one tile: i = 2*chunk + half
   float l[2], mref[2];   // running row sum (this lane's 32 kv columns of every tile) and reference (log2 units)
   float mbase;           // what an unmasked entry of the C-operand tile M holds: -m_ref in a FAST pass, 0 in a GENERAL one
-  f32x2 lab[2];          // the tile's partial sums (even, odd register of each pair): one v_pk_add_f32 per pair
-  f32x2 t[2][2];         // exp results in flight: [stream][pair parity] = (element 0, element 1)
-  f32x2 en[2], ef[2], eq[2];   // FAST pass, per stream: floor of the pair's scores (then as int32), their fractions, the polynomial
-  f32x2 c32, c10;        // exp2 polynomial coefficients (c3, c2), (c1, c0)
+  float la[2], lb[2];    // the tile's partial sums (even / odd register of each pair)
+  float t[2][2][2];      // exp results in flight: [stream][pair parity][element]
   uint32_t dko[4], dvo[4];   // per-piece LDS-DMA source offsets within a tile (constant)
   uint32_t kbase, vbase, kaddr, vaddr[4];
   int hi;
@@ -235,9 +233,7 @@ struct Ctx {
     // register r of half h holds kv row 32 h + 8 (r >> 2) + (r & 3) + 4 hi: one compare of 4 hi against a scalar per register
     // (written as asm so that the 32 compares do not all stay live in SGPR pairs at once)
     const int hi4 = 4 * hi;
-    // (-1e30, not -inf: the FAST pass's exp2 computes f = s - floor(s), which is NaN for -inf; floor(-1e30) -> ldexp(q, INT_MIN) = 0 exactly,
-    // and the GENERAL pass's v_exp_f32 underflows to 0 just the same)
-    const float ninf = -1e30f, zero = mbase;
+    const float ninf = -INFINITY, zero = mbase;
     Ctx* self = this;
     sfor<32>([self, hi4, ninf, zero, valid](auto ii) {
       constexpr int i = decltype(ii)::value, h = i >> 4, r = i & 15;
@@ -290,48 +286,26 @@ struct Ctx {
 
   // ---------------------------------------------------------------- softmax streams (placement: attn_w64_sched.inc)
   // pair q of stream X: registers e, e+1 of S_X[h]; packed into word wd of P_X[ks]
-  // FAST pass: p = 2^s WITHOUT the transcendental unit (round 5).  One v_exp_f32 per score was the single most expensive
-  // instruction of the loop on this power-limited chip: replaced by four plain VALU ops in a timing mock the whole step ran 16.6 %
-  // faster (profiles/r05g_attn_exp_polynomial_mock.log).  s = n + f, n = floor(s), f in [0, 1); 2^f by a degree-3 minimax polynomial
-  // (relative error <= 7.5e-5 = 2^-13.7, 26 x below the bf16 rounding of P that follows; tools/fit_exp2_poly.py), scaled by v_ldexp_f32,
-  // which saturates the way exp2 does (n = INT_MIN -> 0: masked rows carry -1e30, not -inf, see set_mask; overflow -> inf, caught by
-  // the end-of-pass check; a NaN score stays NaN through f).  Per PAIR of scores (two consecutive accumulator registers = one 64-bit
-  // operand): e0 = 2 floors, f = s - n (packed), 2 converts; e1 = 3 packed FMAs, 2 ldexp; a0 = one packed add into (la, lb); c.
-  // GENERAL pass: v_sub + v_exp_f32 per score as before (it runs for the blocks the FAST window cannot hold).
-  template <int MODE, int X, int Q> MMPL_DEV void sm_e0() {
+  template <int MODE, int X, int Q, int EL> MMPL_DEV void sm_e() {
     if constexpr (W64_ABL & (2 | 32)) return;
-    constexpr int h = Q >> 3, e = (Q & 7) * 2;
-    if constexpr (MODE == 0) {
-      const f32x2 sp = __builtin_shufflevector(S[X][h], S[X][h], e, e + 1);
-      asm volatile("v_floor_f32 %0, %1" : "=v"(en[X][0]) : "v"(S[X][h][e]));
-      asm volatile("v_floor_f32 %0, %1" : "=v"(en[X][1]) : "v"(S[X][h][e + 1]));
-      asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(ef[X]) : "v"(sp), "v"(en[X]));
-      asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(en[X][0]));
-      asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(en[X][1]));
-    } else {
-      asm volatile("v_sub_f32 %0, %1, %2\n\tv_exp_f32 %0, %0" : "=&v"(t[X][Q & 1][0]) : "v"(S[X][h][e]), "v"(mref[X]));
-    }
+    constexpr int h = Q >> 3, e = (Q & 7) * 2 + EL;
+    if constexpr (MODE == 0)
+      asm volatile("v_exp_f32 %0, %1" : "=v"(t[X][Q & 1][EL]) : "v"(S[X][h][e]));
+    else
+      asm volatile("v_sub_f32 %0, %1, %2\n\tv_exp_f32 %0, %0" : "=&v"(t[X][Q & 1][EL]) : "v"(S[X][h][e]), "v"(mref[X]));
   }
-  template <int MODE, int X, int Q> MMPL_DEV void sm_e1() {
-    if constexpr (W64_ABL & (2 | 32)) return;
-    constexpr int h = Q >> 3, e = (Q & 7) * 2;
-    if constexpr (MODE == 0) {
-      // Horner: ((c3 f + c2) f + c1) f + c0; op_sel picks the coefficient's half for BOTH lanes of the packed op
-      asm volatile("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(eq[X]) : "v"(ef[X]), "v"(c32));
-      asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(eq[X]) : "v"(ef[X]), "v"(c10));
-      asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,0,1] op_sel_hi:[1,1,1]" : "+v"(eq[X]) : "v"(ef[X]), "v"(c10));
-      asm volatile("v_ldexp_f32 %0, %1, %2" : "=v"(t[X][Q & 1][0]) : "v"(eq[X][0]), "v"(en[X][0]));
-      asm volatile("v_ldexp_f32 %0, %1, %2" : "=v"(t[X][Q & 1][1]) : "v"(eq[X][1]), "v"(en[X][1]));
-    } else {
-      asm volatile("v_sub_f32 %0, %1, %2\n\tv_exp_f32 %0, %0" : "=&v"(t[X][Q & 1][1]) : "v"(S[X][h][e + 1]), "v"(mref[X]));
-    }
-  }
+  template <int MODE, int X, int Q> MMPL_DEV void sm_e0() { sm_e<MODE, X, Q, 0>(); }
+  template <int MODE, int X, int Q> MMPL_DEV void sm_e1() { sm_e<MODE, X, Q, 1>(); }
   template <int MODE, int X, int Q> MMPL_DEV void sm_a0() {
     if constexpr (W64_ABL & (2 | 64)) return;
-    if constexpr (Q == 0 && MODE == 1) lab[X] = t[X][0];
-    else asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(lab[X]) : "v"(t[X][Q & 1]));
+    if constexpr (Q == 0 && MODE == 1) la[X] = t[X][0][0];
+    else asm volatile("v_add_f32 %0, %0, %1" : "+v"(la[X]) : "v"(t[X][Q & 1][0]));
   }
-  template <int MODE, int X, int Q> MMPL_DEV void sm_a1() {}       // (the pair's two row-sum adds are one packed add: sm_a0)
+  template <int MODE, int X, int Q> MMPL_DEV void sm_a1() {
+    if constexpr (W64_ABL & (2 | 64)) return;
+    if constexpr (Q == 0 && MODE == 1) lb[X] = t[X][0][1];
+    else asm volatile("v_add_f32 %0, %0, %1" : "+v"(lb[X]) : "v"(t[X][Q & 1][1]));
+  }
   template <int MODE, int X, int Q> MMPL_DEV void sm_c() {
     if constexpr (W64_ABL & (2 | 128)) return;
     constexpr int ks = Q >> 2, wd = Q & 3;
@@ -381,7 +355,7 @@ struct Ctx {
   }
   template <int MODE, int X> MMPL_DEV void finish() {
     if constexpr (MODE == 0 || (W64_ABL & (2 | 4 | 32 | 64 | 128))) return;     // FAST: la / lb run on; timing ablations: no slow path
-    float lt = lab[X][0] + lab[X][1];
+    float lt = la[X] + lb[X];
     if (__builtin_expect(first[X] || __any(!(lt <= BOUND_GEN)), 0)) lt = slow<X>(lt);
     l[X] += lt;
   }
@@ -395,9 +369,7 @@ template <int MODE> MMPL_DEV void w64_pass(Ctx& k) {
   const int T = k.T;
   sfor<128>([](auto ii) { asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(AO + decltype(ii)::value)); });
   k.l[0] = k.l[1] = 0.f;
-  k.lab[0] = k.lab[1] = f32x2{0.f, 0.f};
-  k.c32 = f32x2{0.07802403102606466f, 0.22606707273040244f};      // 2^f on [0, 1): c3, c2, c1, c0 (tools/fit_exp2_poly.py: max relative error 7.49e-5)
-  k.c10 = f32x2{0.6958339921071405f, 0.999925125546444f};
+  k.la[0] = k.la[1] = k.lb[0] = k.lb[1] = 0.f;
   k.mref[0] = k.mref[1] = 0.f;
   k.mbase = 0.f;
   k.first[0] = k.first[1] = 1;
@@ -566,7 +538,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     bool bad = false;
 #pragma unroll
     for (int X = 0; X < 2; ++X) {
-      k.l[X] = k.lab[X][0] + k.lab[X][1];
+      k.l[X] = k.la[X] + k.lb[X];
       const float l_tot = k.l[X] + __shfl_xor(k.l[X], 32, 64);
       bad |= !(l_tot >= FAST_L_MIN && l_tot <= FAST_L_MAX);
     }

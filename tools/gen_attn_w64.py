@@ -25,12 +25,8 @@ OUT = os.path.join(os.path.dirname(HERE), "mmpl_amd", "csrc", "attn_w64_sched.in
 # Issue-slot weights and slots per gap besides the MFMA.  Measured with the timing build (tools/w64_gen_sweep.sh, shader cycles per
 # KV tile of the steady loop, 14B/720p stage 3): BUDGET 5.5 -> 2480, 5.0 -> 2424, 6.0 -> 2545, 7.0 -> 2568 (floor: 64 MFMAs = 2114);
 # 4.5 does not fit stream 1 into phase A.
-# Round 5: the FAST pass computes exp2 by a polynomial on the plain VALU (attn_w64.hip sm_e0 / sm_e1: 5 instructions each per PAIR of
-# scores) and the pair's two row-sum adds are one packed add (a0; a1 is empty): 12 instructions per pair where there were 5, so a gap
-# now carries up to ~9 of them.  Issue slots are no longer what limits the loop (the power cap is: profiles/r05g_*, r05h_*).
-W_EXP, W_VALU = float(os.environ.get("W64_WEXP", 5.0)), 1.0
-W_OP = {"e0": W_EXP, "e1": W_EXP, "a0": W_VALU, "a1": 0.0, "c": W_VALU}
-BUDGET = float(os.environ.get("W64_BUDGET", 10.0))
+W_EXP, W_VALU = float(os.environ.get("W64_WEXP", 1.5)), 1.0
+BUDGET = float(os.environ.get("W64_BUDGET", 5.0))
 
 # ---- fixed fillers: (flag, statement, slots)
 A_FIXED = {g: [] for g in range(32)}
@@ -40,7 +36,7 @@ B_FIXED = {g: [] for g in range(32)}
 # time, 8 times in a row: measured 145 cycles per tile of issue back-pressure; spread out they cost ~0.
 K_DMA = [int(x) for x in os.environ.get("W64_KDMA", "4,8,12,16").split(",")]
 V_DMA = [int(x) for x in os.environ.get("W64_VDMA", "20,24,28,36").split(",")]
-W_DMA = float(os.environ.get("W64_WDMA", 4.0))    # (round 4: BUDGET - 1 = 4 of 5 slots)
+W_DMA = float(os.environ.get("W64_WDMA", BUDGET - 1))
 
 
 def _fixed(g):
@@ -92,12 +88,10 @@ class Stream:
             return None
         qa = self.ac_done // 3
         if qa < 16 and qa in self.e_gap and self.e_gap[qa] < gap and gap >= self.c_earliest(qa):
-            op = ("a0", "a1", "c")[self.ac_done % 3]
-            return (op, qa, W_OP[op])
+            return (("a0", "a1", "c")[self.ac_done % 3], qa, W_VALU)
         qe = self.e_done // 2
         if qe < 16 and qe - qa < 2:
-            op = ("e0", "e1")[self.e_done % 2]
-            return (op, qe, W_OP[op])
+            return (("e0", "e1")[self.e_done % 2], qe, W_EXP)
         return None
 
     def place(self, op, q, gap):
@@ -160,7 +154,7 @@ def emit():
         base = 0 if ph == "A" else 32
         lines.append(f"template <int MODE, bool QK, bool PV, bool S0, bool S1> MMPL_DEV void w64_phase_{ph.lower()}(Ctx& k) {{")
         for g in range(32):
-            load = BUDGET - cap[base + g] + sum(W_OP[o[1]] for o in placed[base + g])
+            load = BUDGET - cap[base + g] + sum((W_EXP if o[1][0] == "e" else W_VALU) for o in placed[base + g])
             lines.append(f"  // ---- gap {g}: {load:.1f} slots")
             if g < 16:
                 lines.append(f"  if constexpr (QK) k.template mfma_qk<{x}, {g}>();")
@@ -194,7 +188,7 @@ def emit():
     with open(OUT, "w") as fh:
         fh.write("\n".join(lines))
     # report
-    tot = [BUDGET - cap[g] + sum(W_OP[o[1]] for o in placed[g]) for g in range(64)]
+    tot = [BUDGET - cap[g] + sum((W_EXP if o[1][0] == "e" else W_VALU) for o in placed[g]) for g in range(64)]
     print("slots per gap A:", " ".join(f"{t:.1f}" for t in tot[:32]))
     print("slots per gap B:", " ".join(f"{t:.1f}" for t in tot[32:]))
     print("stream 1 last gap", last[1], " stream 0 last gap", last[0], " mean", sum(tot) / 64)

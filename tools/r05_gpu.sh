@@ -120,20 +120,11 @@ for f in ('x3','x8'):
         python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae $a > $out/sh_tmp.json 2>> $out/bench.err; line $out/sh_tmp.json "14B/720p [$a]" >> $out/bench_share_block0_ab.log
         python bench.py --res 480p --steps 8 --warmup 4 --no-cpu-baseline --no-vae $a > $out/sh_tmp.json 2>> $out/bench.err; line $out/sh_tmp.json "14B/480p [$a]" >> $out/bench_share_block0_ab.log
       done; cat $out/bench_share_block0_ab.log ;;
-    expmock)     # attention: v_exp_f32 replaced by four plain VALU ops (timing mock of a polynomial exp2), in situ, alternating with the shipping build
-      for f in "" "-DW64_ABL=512" "" "-DW64_ABL=512"; do
-        build "$f"; python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae > $out/exp_tmp.json 2>> $out/bench.err; line $out/exp_tmp.json "[$f]" >> $out/attn_exp_polynomial_mock.log
-      done; build ""; cat $out/attn_exp_polynomial_mock.log ;;
     groupsweep)  # M-tile group of the block order (MMPL_GEMM_GROUP) on the four 14B / 720p block shapes, at M = 25200 and 21600
       for m in 25200 21600; do for g in 0 2 3 4 6 8; do
         echo "== M=$m MMPL_GEMM_GROUP=$g (0 = the launcher's choice)" >> $out/gemm_group_sweep.log
         MMPL_GEMM_GROUP=$g BENCH_SHAPES=$(echo $BIG | sed "s/25200/$m/g") timeout 300 python tools/bench_kernels.py gemm --iters 5 2>&1 | grep "^gemm" | sed 's/|  + split.*//' >> $out/gemm_group_sweep.log
       done; done; cat $out/gemm_group_sweep.log ;;
-    schedsweep)  # attention schedule generator settings (issue-slot budget per MFMA gap, DMA weight) with the polynomial exp2, in situ
-      for cfg in "10:4" "11:4" "12:4" "11:10" "9.5:3" "10:4"; do
-        W64_BUDGET=${cfg%%:*} W64_WDMA=${cfg##*:} python tools/gen_attn_w64.py > $out/gen.log 2>&1 || { echo "budget $cfg: does not fit" >> $out/attn_sched_sweep.log; continue; }
-        build ""; python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae > $out/ss_tmp.json 2>> $out/bench.err; line $out/ss_tmp.json "budget:wdma $cfg ($(tail -1 $out/gen.log))" >> $out/attn_sched_sweep.log
-      done; git checkout mmpl_amd/csrc/attn_w64_sched.inc 2>/dev/null || W64_BUDGET=10 W64_WDMA=4 python tools/gen_attn_w64.py > /dev/null; build ""; cat $out/attn_sched_sweep.log ;;
     *) echo "unknown step $step" ;;
   esac
   clean_cores
