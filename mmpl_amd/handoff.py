@@ -168,6 +168,8 @@ class ChunkHandoff:
         self._keep: List = []                  # control tensors / requests that must outlive their call
         self.stats = {}
         self.loopback = bool(loopback) and self.world == 1
+        if self.loopback and self.backend == "gloo":
+            raise ValueError("ChunkHandoff(loopback=True) needs a transport that can send to its own rank (RCCL); gloo has no pair to oneself")
         self.handshake = ready_handshake and (self.world > 1 or self.loopback)
         self._ctl = None
         self._self_ready = {}                  # loopback: chunk -> threading.Event of our own announcement
