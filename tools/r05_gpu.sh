@@ -125,6 +125,8 @@ for f in ('x3','x8'):
         echo "== M=$m MMPL_GEMM_GROUP=$g (0 = the launcher's choice)" >> $out/gemm_group_sweep.log
         MMPL_GEMM_GROUP=$g BENCH_SHAPES=$(echo $BIG | sed "s/25200/$m/g") timeout 300 python tools/bench_kernels.py gemm --iters 5 2>&1 | grep "^gemm" | sed 's/|  + split.*//' >> $out/gemm_group_sweep.log
       done; done; cat $out/gemm_group_sweep.log ;;
+    n2gloo14)    # the DEFAULT N = 2 line at 14B scale (480p so that two ranks fit one GPU), gloo: the budgeted step count and the scaling at a realistic size
+      timeout 1500 python bench.py --gpus 2 --dist-backend gloo --model 14B --res 480p --no-cpu-baseline > $out/bench_default_n2_gloo_14B_480p.json 2>> $out/bench.err; tail -c 1800 $out/bench_default_n2_gloo_14B_480p.json ;;
     *) echo "unknown step $step" ;;
   esac
   clean_cores
