@@ -422,7 +422,7 @@ struct EpiIn {                 // what a wave's 128 x 64 sub-tile epilogue reads
   uint2 bias4[4];              // MFMA side: this lane's 4 output columns of each of the 4 column fragments
   uint4 res8[16];              // row-major side: the residual of row step u (8 columns)
   uint4 gate_lo, gate_hi;      // the two candidate per-frame gate rows
-  int f_lo;
+  int m_split;                 // first row of the sub-tile that belongs to the SECOND candidate frame (rows below it: gate_lo)
 };
 // The bias FIRST: loads return in order and the staging needs nothing but the bias -- issued behind the 16 residual loads (round 4)
 // its `s_waitcnt` was a vmcnt(0) that held the whole staging back for an HBM round trip of the residual (seen in the ISA).
@@ -460,11 +460,12 @@ MMPL_DEV void epi_load_res(const GemmArgs& g, EpiIn& in, int mw, int nw, int lan
   if (U0 != 0) return;
   in.gate_lo = uint4{0u, 0u, 0u, 0u};
   in.gate_hi = in.gate_lo;
-  in.f_lo = 0;
+  in.m_split = 0;
   if (EPI == EPI_GATE_RES && n_ok) {
-    in.f_lo = min(mw, g.M - 1) / g.rows_per_frame;
+    const int f_lo = min(mw, g.M - 1) / g.rows_per_frame;
     const int f_hi = min(mw + 127, g.M - 1) / g.rows_per_frame;
-    in.gate_lo = *reinterpret_cast<const uint4*>(g.gate + (size_t)in.f_lo * g.gate_frame_stride + n);
+    in.m_split = (f_lo + 1) * g.rows_per_frame;                      // (one division per sub-tile instead of one per row step)
+    in.gate_lo = *reinterpret_cast<const uint4*>(g.gate + (size_t)f_lo * g.gate_frame_stride + n);
     in.gate_hi = *reinterpret_cast<const uint4*>(g.gate + (size_t)f_hi * g.gate_frame_stride + n);
   }
 }
@@ -511,7 +512,7 @@ MMPL_DEV void epi_finish(const GemmArgs& g, const EpiIn& in, const char* stg, in
     uint4 ov = yv;
     if (HAS_RES) {
       uint4 ev = uint4{0u, 0u, 0u, 0u};
-      if (EPI == EPI_GATE_RES) ev = (m / g.rows_per_frame == in.f_lo) ? in.gate_lo : in.gate_hi;
+      if (EPI == EPI_GATE_RES) ev = (m < in.m_split) ? in.gate_lo : in.gate_hi;
       const uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w}, xw[4] = {in.res8[u].x, in.res8[u].y, in.res8[u].z, in.res8[u].w}, ew[4] = {ev.x, ev.y, ev.z, ev.w};
       float v[8];
 #pragma unroll
@@ -1196,8 +1197,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
       epi_load_bias<EPI>(g, in1, nw0 + 64, lane_e);
       // (the first NPRE row steps: the register file has no room for all 16 beside the second half's accumulators -- with more, hipcc
-      // spills or, worse, parks values in the accumulator file that still holds them: tests/test_isa_audit.py)
-      constexpr int NPRE = EPI == EPI_GATE_RES ? 0 : 8;
+      // spills or, worse, parks values in the accumulator file that still holds them: tests/test_isa_audit.py.  The gated epilogue only
+      // fits since its per-row `m / rows_per_frame` became one compare against EpiIn::m_split.)
+      constexpr int NPRE = 8;
       epi_load_res<EPI, 0, NPRE>(g, in1, mw, nw0 + 64, lane_e);
       epi_finish<EPI>(g, in0, stg0, mw, nw0, lane_e);
       {

@@ -127,6 +127,11 @@ for f in ('x3','x8'):
       done; done; cat $out/gemm_group_sweep.log ;;
     n2gloo14)    # the DEFAULT N = 2 line at 14B scale (480p so that two ranks fit one GPU), gloo: the budgeted step count and the scaling at a realistic size
       timeout 1500 python bench.py --gpus 2 --dist-backend gloo --model 14B --res 480p --no-cpu-baseline > $out/bench_default_n2_gloo_14B_480p.json 2>> $out/bench.err; tail -c 1800 $out/bench_default_n2_gloo_14B_480p.json ;;
+    v8all)       # v8 (now with the second half's residual rows in flight under the first half's stores) on EVERY large GEMM vs the launcher's choice (v8 for N >= 8192 only)
+      for e in "A=0" "MMPL_GEMM_V8=1" "A=0" "MMPL_GEMM_V8=1"; do
+        env $e python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae --profile-all > $out/v8_tmp.json 2>> $out/bench.err; line $out/v8_tmp.json "14B/720p [$e]" >> $out/gemm_v8_everywhere_ab.log
+        echo "== $e standalone" >> $out/gemm_v8_everywhere_ab.log; env $e BENCH_SHAPES=$BIG timeout 300 python tools/bench_kernels.py gemm --iters 5 2>&1 | grep "^gemm" | sed 's/|  + split.*//' >> $out/gemm_v8_everywhere_ab.log
+      done; cat $out/gemm_v8_everywhere_ab.log ;;
     *) echo "unknown step $step" ;;
   esac
   clean_cores
