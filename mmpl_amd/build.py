@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmmpl_hip.so")
 SOURCES = ["device_state.hip", "gemm.hip", "attention.hip", "attn_w64.hip", "elementwise.hip", "vae_kernels.hip", "vae.hip", "t5.hip", "i2v.hip", "probe.hip", "api.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + os.environ.get("MMPL_EXTRA_HIPCC_FLAGS", "").split()
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed"] + os.environ.get("MMPL_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _hipcc() -> str:

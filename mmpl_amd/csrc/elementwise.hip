@@ -80,74 +80,223 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
   }
 }
 
-// ------------------------------------------------------------------ QK RMSNorm (+RoPE, +KV page write)
-// one wave per token row.  Each lane's 16-B chunks sit at the same position inside a head for every
-// iteration (64*8 elements = 4 heads per sweep), so its 4 rotary pairs' cos/sin are loaded once per row.
-template <int NIT>
-__global__ __launch_bounds__(256) void qknorm_kernel(QkNormArgs a) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= a.rows) return;
-  const int lane = threadIdx.x & 63;
+// ------------------------------------------------------------------ pipelined row passes: LayerNorm for the big stages, QK RMSNorm (+RoPE, +KV page write)
+// The one-row-per-wave form above runs load -> statistics -> output -> store in lock step on every wave of the chip (a launch
+// is ~6 rounds of resident blocks), so HBM idles while the VALU works and vice versa: 3.9 TB/s on 25 200 x 5120, and the q / k
+// pass -- two rows per wave, one after the other, 172 registers -- 2.8 TB/s.  Here a block owns a contiguous range of 4-row
+// groups and every wave has the NEXT row's 16 B loads in flight while it works on the current one; the row stays PACKED in
+// registers (NIT x 16 B per lane) and is unpacked once per pass; q rows and k rows go to different blocks (grid.y).  vmcnt is
+// in order on gfx9, so nothing the current row needs may be loaded from global memory behind that prefetch: the per-column
+// vectors (modulation / affine / gain) are staged in LDS once per block (and per frame), RoPE factors ride with the prefetch.
+// Same arithmetic, rounding for rounding (hashes of the outputs: profiles/r05r_*): 4.7 / 4.6 TB/s.
+MMPL_DEV void keep_packed(uint4& u) { asm volatile("" : "+v"(u.x), "+v"(u.y), "+v"(u.z), "+v"(u.w)); }
+
+// FULL: d == 512 NIT and rows % 4 == 0 (every model shape): no per-chunk / per-row predicate anywhere, so the number of
+// memory operations between a prefetch and its use is a compile-time constant and the compiler's s_waitcnt vmcnt(N) lets the
+// younger ones stay in flight (with predicated loads it has to fall back to vmcnt(0), which would wait for the prefetch too).
+template <int NIT, bool FULL>
+MMPL_DEV void load_row(uint4 (&u)[NIT], const bf16_t* p, int lane, int nchunk, bool live) {
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int ch = lane + 64 * it;
+    if (FULL) u[it] = *reinterpret_cast<const uint4*>(p + ch * 8);
+    else u[it] = (live && ch < nchunk) ? *reinterpret_cast<const uint4*>(p + ch * 8) : uint4{0u, 0u, 0u, 0u};
+  }
+}
+
+template <int NIT, bool FULL>
+MMPL_DEV void layernorm_row(const LnArgs& a, uint4 (&cur)[NIT], const uint4 (*sm)[NIT * 64], int staged, int row, int lane, int nchunk) {
+#pragma clang fp contract(off)                                    // as layernorm_kernel is compiled: no fma but the affine one
+  float sum = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    float v[8];
+    unpack8(cur[it], v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum += v[j];                      // the padding chunks add +0
+  }
+  const float mean = wave_sum(sum) / (float)a.d;
+  float sq = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    keep_packed(cur[it]);
+    const bool ok = FULL || lane + 64 * it < nchunk;
+    float v[8];
+    unpack8(cur[it], v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float dlt = ok ? v[j] - mean : 0.f; sq += dlt * dlt; }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)a.d + a.eps);
+  bf16_t* yp = a.y + (size_t)row * a.ldy;
+  const int frame = a.w ? 0 : row / a.rows_per_frame;             // != staged only where a group straddles two frames
+  const bf16_t* p0 = a.w ? a.w : a.scale + (size_t)frame * a.mod_frame_stride;
+  const bf16_t* p1 = a.w ? a.b : a.shift + (size_t)frame * a.mod_frame_stride;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int ch = lane + 64 * it;
+    if (!FULL && ch >= nchunk) continue;
+    keep_packed(cur[it]);
+    float v[8], c0[8], c1[8], o[8];
+    unpack8(cur[it], v);
+    if (FULL || frame == staged) {                                // FULL: rows_per_frame % 4 == 0, a group never straddles
+      unpack8(sm[0][ch], c0);
+      unpack8(sm[1][ch], c1);
+    } else {
+      unpack8(*reinterpret_cast<const uint4*>(p0 + ch * 8), c0);
+      unpack8(*reinterpret_cast<const uint4*>(p1 + ch * 8), c1);
+    }
+    if (a.w) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf((v[j] - mean) * rstd, c0[j], c1[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float n = rbf((v[j] - mean) * rstd);                // norm output is a bf16 tensor
+        const float s1 = rbf(1.0f + c0[j]);                       // (1 + e) is a bf16 tensor
+        o[j] = rbf(n * s1) + c1[j];                               // product rounds, sum rounds at pack
+      }
+    }
+    *reinterpret_cast<uint4*>(yp + ch * 8) = pack8(o);
+  }
+}
+
+template <int NIT, bool FULL>
+__global__ __launch_bounds__(256) void layernorm_pipelined_kernel(LnArgs a, int groups_per_block) {
+  __shared__ uint4 sm[2][NIT * 64];                               // scale | w and shift | b of the staged frame
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave-uniform: row, frame, page pointers stay scalar
   const int nchunk = a.d >> 3;
-  const int lf = a.rope ? row / a.rows_per_frame : 0;             // local frame
-  const int tok = a.rope ? row - lf * a.rows_per_frame : row;     // token inside the frame
-  float cs[4], sn[4];
-  if (a.rope) {
-    const int gy = tok / a.grid_w, gx = tok - gy * a.grid_w, ft = a.frame_ids[lf];
+  const int ngroups = (a.rows + 3) >> 2;
+  int g = blockIdx.x * groups_per_block;
+  const int g_end = min(g + groups_per_block, ngroups);
+  if (g >= g_end) return;
+  int staged = -1;
+  uint4 cur[NIT], nxt[NIT];
+  load_row<NIT, FULL>(cur, a.x + (size_t)(4 * g + wv) * a.ldx, lane, nchunk, 4 * g + wv < a.rows);
+  for (;; ++g) {
+    const int row = 4 * g + wv;
+    const bool more = g + 1 < g_end;                              // block-uniform
+    const int gframe = a.w ? 0 : (4 * g) / a.rows_per_frame;      // block-uniform
+    if (gframe != staged) {                                       // (before the prefetch: a conditional load between the prefetch and
+      __syncthreads();                                            //  its use would make the compiler wait with vmcnt(0) on every path)
+      const bf16_t* p0 = a.w ? a.w : a.scale + (size_t)gframe * a.mod_frame_stride;
+      const bf16_t* p1 = a.w ? a.b : a.shift + (size_t)gframe * a.mod_frame_stride;
+      for (int i = threadIdx.x; i < nchunk; i += 256) {
+        sm[0][i] = *reinterpret_cast<const uint4*>(p0 + i * 8);
+        sm[1][i] = *reinterpret_cast<const uint4*>(p1 + i * 8);
+      }
+      __syncthreads();
+      staged = gframe;
+    }
+    if (more) load_row<NIT, FULL>(nxt, a.x + (size_t)(row + 4) * a.ldx, lane, nchunk, row + 4 < a.rows);
+    asm volatile("" ::: "memory");                                // the prefetch is issued here, not where it is consumed
+    if (FULL || row < a.rows) layernorm_row<NIT, FULL>(a, cur, sm, staged, row, lane, nchunk);
+    if (!more) break;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) { cur[it] = nxt[it]; keep_packed(cur[it]); }   // "used" here: the wait for the prefetch lands before the next one is issued
+  }
+}
+
+struct RopeRow { float cs[4], sn[4]; int lf, tok; };
+MMPL_DEV void rope_row(const QkNormArgs& a, int row, int lane, bool live, RopeRow& r) {
+  r.lf = a.rope ? row / a.rows_per_frame : 0;                     // local frame
+  r.tok = a.rope ? row - r.lf * a.rows_per_frame : row;           // token inside the frame
+  if (a.rope && live) {
+    const int gy = r.tok / a.grid_w, gx = r.tok - gy * a.grid_w, ft = a.frame_ids[r.lf];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int p = 4 * (lane & 15) + j;                          // rotary pair index inside the head, 0..63
       const int pos = p < 22 ? ft : (p < 43 ? gy : gx);           // split (22, 21, 21): causal_fps_model.py:31
-      cs[j] = a.cos_tab[pos * 64 + p];
-      sn[j] = a.sin_tab[pos * 64 + p];
+      r.cs[j] = a.cos_tab[pos * 64 + p];
+      r.sn[j] = a.sin_tab[pos * 64 + p];
     }
   }
-  const int n_mat = a.k ? 2 : 1;
-  for (int which = 0; which < n_mat; ++which) {
-    const bf16_t* src = which == 0 ? a.q + (size_t)row * a.ldq : a.k + (size_t)row * a.ldk;
-    const bf16_t* gain = which == 0 ? a.wq : a.wk;
-    float v[NIT][8];
-    float sq = 0.f;
+}
+
+template <int NIT, bool FULL>
+MMPL_DEV void qknorm_row(const QkNormArgs& a, uint4 (&cur)[NIT], const uint4* sg, const RopeRow& rc, bf16_t* dst, float qs, int lane, int nchunk) {
+#pragma clang fp contract(off)                                    // the two fmas of the rotation are written out below
+  float sq = 0.f;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int ch = lane + 64 * it;
-      if (ch < nchunk) {
-        unpack8(*reinterpret_cast<const uint4*>(src + ch * 8), v[it]);
+  for (int it = 0; it < NIT; ++it) {
+    float v[8];
+    unpack8(cur[it], v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sq += v[it][j] * v[it][j];
-      }
-    }
-    const float rr = rsqrtf(wave_sum(sq) / (float)a.d + a.eps);
-    bf16_t* dst = which == 0 ? a.q + (size_t)row * a.ldq
-                             : (a.k_dst[lf] + (size_t)tok * a.d);
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int ch = lane + 64 * it;
-      if (ch >= nchunk) continue;
-      float w[8], o[8];
-      unpack8(*reinterpret_cast<const uint4*>(gain + ch * 8), w);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = rbf(rbf(v[it][j] * rr) * w[j]);   // norm.type_as(x) * weight
-      if (a.rope) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float re = o[2 * j], im = o[2 * j + 1];
-          o[2 * j] = re * cs[j] - im * sn[j];
-          o[2 * j + 1] = re * sn[j] + im * cs[j];
-        }
-      }
-      if (which == 0 && a.q_scale != 0.f) {      // softmax scale folded into q while it is still fp32 (attn_w64.hip)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] *= a.q_scale;
-      }
-      *reinterpret_cast<uint4*>(dst + ch * 8) = pack8(o);
-    }
+    for (int j = 0; j < 8; ++j) sq += v[j] * v[j];                // the padding chunks add +0
   }
-  if (a.v) {  // V is copied unchanged into its page
-    const bf16_t* src = a.v + (size_t)row * a.ldv;
-    bf16_t* dst = a.v_dst[lf] + (size_t)tok * a.d;
-    for (int ch = lane; ch < nchunk; ch += 64)
-      *reinterpret_cast<uint4*>(dst + ch * 8) = *reinterpret_cast<const uint4*>(src + ch * 8);
+  const float rr = rsqrtf(wave_sum(sq) / (float)a.d + a.eps);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int ch = lane + 64 * it;
+    if (!FULL && ch >= nchunk) continue;
+    keep_packed(cur[it]);
+    float v[8], w[8], o[8];
+    unpack8(cur[it], v);
+    unpack8(sg[ch], w);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = rbf(rbf(v[j] * rr) * w[j]);       // norm.type_as(x) * weight
+    if (a.rope) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // which product of each sum is rounded on its own is what hipcc's contraction happened to give the one-row-per-wave
+        // kernel this one replaces (read off its ISA: per 16-byte chunk one unfused difference, then fmas) -- written out so
+        // that q and the K pages stay bit-identical to what every recorded parity number was measured on
+        const float re = o[2 * j], im = o[2 * j + 1], cs = rc.cs[j], sn = rc.sn[j];
+        o[2 * j] = j == 0 ? re * cs - im * sn : __builtin_fmaf(re, cs, -(im * sn));
+        o[2 * j + 1] = j == 3 ? __builtin_fmaf(re, sn, im * cs) : __builtin_fmaf(im, cs, re * sn);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] *= qs;
+    *reinterpret_cast<uint4*>(dst + ch * 8) = pack8(o);
+  }
+}
+
+template <int NIT, bool FULL>
+__global__ __launch_bounds__(256) void qknorm_kernel(QkNormArgs a, int groups_per_block) {
+  __shared__ uint4 sg[NIT * 64];                                  // the gain vector of this block's matrix
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave-uniform: row, frame, page pointers stay scalar
+  const int nchunk = a.d >> 3;
+  const int which = blockIdx.y;                                   // 0 q, 1 k, 2 v
+  const int ngroups = (a.rows + 3) >> 2;
+  int g = blockIdx.x * groups_per_block;
+  const int g_end = min(g + groups_per_block, ngroups);
+  if (g >= g_end) return;
+  if (which == 2) {                                               // V is copied unchanged into its page
+    for (; g < g_end; ++g) {
+      const int row = 4 * g + wv;
+      if (row >= a.rows) break;
+      const int lf = a.rope ? row / a.rows_per_frame : 0, tok = a.rope ? row - lf * a.rows_per_frame : row;
+      const bf16_t* src = a.v + (size_t)row * a.ldv;
+      bf16_t* dst = a.v_dst[lf] + (size_t)tok * a.d;
+      for (int ch = lane; ch < nchunk; ch += 64)
+        *reinterpret_cast<uint4*>(dst + ch * 8) = *reinterpret_cast<const uint4*>(src + ch * 8);
+    }
+    return;
+  }
+  const bf16_t* gain = which == 0 ? a.wq : a.wk;
+  for (int i = threadIdx.x; i < nchunk; i += 256) sg[i] = *reinterpret_cast<const uint4*>(gain + i * 8);
+  const bf16_t* base = which == 0 ? a.q : a.k;
+  const int ld = which == 0 ? a.ldq : a.ldk;
+  const float qs = (which == 0 && a.q_scale != 0.f) ? a.q_scale : 1.0f;   // softmax scale folded into q while it is still fp32 (attn_w64.hip)
+  uint4 cur[NIT], nxt[NIT];
+  RopeRow rc, rn;
+  rope_row(a, 4 * g + wv, lane, FULL || 4 * g + wv < a.rows, rc);
+  load_row<NIT, FULL>(cur, base + (size_t)(4 * g + wv) * ld, lane, nchunk, 4 * g + wv < a.rows);
+  __syncthreads();
+  for (;; ++g) {
+    const int row = 4 * g + wv;
+    const bool more = g + 1 < g_end;                              // block-uniform
+    if (more) {
+      rope_row(a, row + 4, lane, FULL || row + 4 < a.rows, rn);   // older than the row's loads: back first
+      load_row<NIT, FULL>(nxt, base + (size_t)(row + 4) * ld, lane, nchunk, row + 4 < a.rows);
+    }
+    asm volatile("" ::: "memory");                                // the prefetch is issued here, not where it is consumed
+    if (FULL || row < a.rows)
+      qknorm_row<NIT, FULL>(a, cur, sg, rc, which == 0 ? a.q + (size_t)row * a.ldq : (a.k_dst[rc.lf] + (size_t)rc.tok * a.d), qs, lane, nchunk);
+    if (!more) break;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) { cur[it] = nxt[it]; keep_packed(cur[it]); }   // as in layernorm_pipelined_kernel
+    rc = rn;
   }
 }
 
@@ -276,20 +425,61 @@ inline int grid_for(size_t n, int block = 256) {
     case 9: case 10: hipLaunchKernelGGL(KERNEL<10>, dim3(((ROWS) + 3) / 4), dim3(256), 0, STREAM, ARGS); break; \
     default: return hipErrorInvalidValue;                                                                  \
   }
+// pipelined kernels: all blocks resident at once (blocks per CU from the occupancy query, cached per instantiation), each with
+// a contiguous range of 4-row groups
+template <typename K>
+static int resident_blocks(K kernel, int* cache) {
+  if (!*cache) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    *cache = per_cu * 8 * mmpl_cus_per_xcd();
+  }
+  return *cache;
+}
+template <typename A>
+static void launch_pipelined(void (*kernel)(A, int), int* cache, const A& a, int rows, int ny, hipStream_t s) {
+  const int ngroups = (rows + 3) / 4, resident = resident_blocks(kernel, cache);
+  int gpb = (ngroups + resident - 1) / resident;
+  hipLaunchKernelGGL(kernel, dim3((ngroups + gpb - 1) / gpb, ny), dim3(256), 0, s, a, gpb);
+}
+#define PIPELINED_CASE(N, KERNEL, ARGS, ROWS, NY, STREAM, FULLV)                                           \
+  { static int c0 = 0, c1 = 0;                                                                             \
+    if (FULLV) launch_pipelined(KERNEL<N, true>, &c1, ARGS, ROWS, NY, STREAM);                             \
+    else launch_pipelined(KERNEL<N, false>, &c0, ARGS, ROWS, NY, STREAM); }
+#define DISPATCH_PIPELINED(NITV, KERNEL, ARGS, ROWS, NY, STREAM, FULLV)                                    \
+  switch (NITV) {                                                                                          \
+    case 1: PIPELINED_CASE(1, KERNEL, ARGS, ROWS, NY, STREAM, FULLV) break;                                \
+    case 2: PIPELINED_CASE(2, KERNEL, ARGS, ROWS, NY, STREAM, FULLV) break;                                \
+    case 3: PIPELINED_CASE(3, KERNEL, ARGS, ROWS, NY, STREAM, FULLV) break;                                \
+    case 4: PIPELINED_CASE(4, KERNEL, ARGS, ROWS, NY, STREAM, FULLV) break;                                \
+    case 5: case 6: PIPELINED_CASE(6, KERNEL, ARGS, ROWS, NY, STREAM, (FULLV) && (NITV) == 6) break;       \
+    case 7: case 8: PIPELINED_CASE(8, KERNEL, ARGS, ROWS, NY, STREAM, (FULLV) && (NITV) == 8) break;       \
+    case 9: case 10: PIPELINED_CASE(10, KERNEL, ARGS, ROWS, NY, STREAM, (FULLV) && (NITV) == 10) break;    \
+    default: return hipErrorInvalidValue;                                                                  \
+  }
 
 hipError_t mmpl_launch_layernorm(const LnArgs& a, hipStream_t s) {
   if (a.rows <= 0) return hipSuccess;
   if (a.d % 8 || a.d > 5120 || a.ldx % 8 || a.ldy % 8) return hipErrorInvalidValue;
   const int nit = (a.d / 8 + 63) / 64;
-  DISPATCH_NIT(nit, layernorm_kernel, a, a.rows, s);
+  // measured (profiles/r05q_*, r05r_*): the pipeline pays from ~6 row groups per block on rows of >= 6 KB (25 200 x 5120: 131 -> 110 us,
+  // 21 600: 110 -> 98); below that its prologue / tail cost more than the overlap returns (7200 x 5120: 32 vs 35 us; 1536-wide rows: 16 vs 18)
+  if (nit >= 6 && a.rows >= 16384) {
+    const bool full = a.d == 512 * nit && a.rows % 4 == 0 && (a.w || a.rows_per_frame % 4 == 0);
+    DISPATCH_PIPELINED(nit, layernorm_pipelined_kernel, a, a.rows, 1, s, full);
+  } else {
+    DISPATCH_NIT(nit, layernorm_kernel, a, a.rows, s);
+  }
   return hipGetLastError();
 }
 
 hipError_t mmpl_launch_qknorm(const QkNormArgs& a, hipStream_t s) {
   if (a.rows <= 0) return hipSuccess;
   if (a.d % 128 || a.d > 5120 || a.ldq % 8 || a.ldk % 8 || a.ldv % 8) return hipErrorInvalidValue;
+  if (a.v && !a.k) return hipErrorInvalidValue;
   const int nit = (a.d / 8 + 63) / 64;
-  DISPATCH_NIT(nit, qknorm_kernel, a, a.rows, s);
+  const bool full = a.d == 512 * nit && a.rows % 4 == 0;
+  DISPATCH_PIPELINED(nit, qknorm_kernel, a, a.rows, 1 + (a.k ? 1 : 0) + (a.v ? 1 : 0), s, full);
   return hipGetLastError();
 }
 

@@ -323,7 +323,9 @@ def test_attention_spiked_scores(lib, variant, spike):
     assert max_abs(o, ref) < 2.0 ** -7 * ref.abs().max().item() + 1e-2 and rel_l2(o, ref) < 1e-2
 
 
-@pytest.mark.parametrize("d,rows,S", [(256, 200, 50), (1536, 97, 97), (5120, 130, 65), (512, 8, 4)])
+@pytest.mark.parametrize("d,rows,S", [(256, 200, 50), (1536, 97, 97), (5120, 130, 65), (512, 8, 4),
+                                      # several row groups per block (the pipelined loop), a frame change inside a block's range:
+                                      (5120, 7224, 1204), (1536, 9 * 1204, 1204), (5120, 7 * 1001, 1001), (1024, 20000, 20000)])
 def test_layernorm_modulate_and_affine(lib, d, rows, S):
     from mmpl_amd import _lib
     from oracle import wan_dit_ref as W
@@ -348,7 +350,9 @@ def test_layernorm_modulate_and_affine(lib, d, rows, S):
     assert bf16_ulp_frac(y, ref, 1) < 1e-3
 
 
-@pytest.mark.parametrize("H,lat,frames", [(2, (8, 12), [3, 10]), (12, (6, 10), [0, 19, 20]), (40, (4, 8), [5])])
+@pytest.mark.parametrize("H,lat,frames", [(2, (8, 12), [3, 10]), (12, (6, 10), [0, 19, 20]), (40, (4, 8), [5]),
+                                          # several row groups per block (the pipelined loop): 7224 rows of 5120 / 1536, and an odd row count
+                                          (40, (56, 86), [0, 1, 2, 7, 19, 20]), (12, (56, 86), [3, 4, 5, 6, 7, 8, 9]), (4, (70, 86), [2, 3, 4, 5, 6])])
 def test_qknorm_rope_kvwrite(lib, H, lat, frames):
     from mmpl_amd import _lib
     from mmpl_amd.dit import DitEngine

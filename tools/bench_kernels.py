@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmarks of the two MFMA kernels on the 14B/720p shapes (dev tool).
-    python tools/bench_kernels.py attn|gemm|all|gemmref|attnref [--iters N]"""
+    python tools/bench_kernels.py attn|gemm|all|gemmref|attnref|elem [--iters N]"""
 import ctypes as C
 import math
 import os
@@ -161,6 +161,54 @@ def gemm_phases(epi=3):
           f"p95 {t[:, 1].quantile(0.95).item():.0f})  epilogue {t[:, 2].mean().item():.0f} (max {t[:, 2].max().item():.0f}) cycles", flush=True)
 
 
+def bench_elem(iters):
+    """the HBM-bound passes of a block at the stage shapes: LayerNorm + modulation (3 per block) and q/k RMS-norm + RoPE + K page write
+    (1 per block; the cross-attention's q norm is the same kernel on q alone).  Prints time, algorithmic GB/s and a hash of the outputs."""
+    import hashlib
+    from mmpl_amd.dit import DitEngine
+
+    def sha(*ts):
+        h = hashlib.sha256()
+        for t in ts:
+            h.update(t.contiguous().view(torch.int16).cpu().numpy().tobytes())
+        return h.hexdigest()[:12]
+
+    for model, d, H, lat, S, frames_list in (("14B/720p", 5120, 40, (90, 160), 3600, (7, 6, 2)), ("1.3B/480p", 1536, 12, (60, 104), 1560, (7, 6, 2))):
+        eng = DitEngine(dict(dim=d, ffn_dim=256, num_heads=H, num_layers=1, text_dim=64), lat[0], lat[1], dev)
+        for nF in frames_list:
+            rows = nF * S
+            torch.manual_seed(nF)
+            x = (torch.randn(rows, d, device=dev) * 3 + 0.5).to(BF)
+            e = (torch.randn(nF, 6, d, device=dev) * 0.3).to(BF)
+            y = torch.empty_like(x)
+            fn = lambda: _lib.check(lib.mmpl_layernorm(_lib.ptr(x), d, _lib.ptr(y), d, rows, d, 1e-6, _lib.ptr(e[:, 1]), _lib.ptr(e[:, 0]), 6 * d, S,
+                                                       None, None, _lib.stream_ptr()))
+            ms = min(timeit(fn, iters), timeit(fn, iters))
+            gb = 2.0 * rows * d * 2 / 1e9
+            h = sha(y)
+            w = (1 + 0.1 * torch.randn(d, device=dev)).to(BF)
+            b = (0.1 * torch.randn(d, device=dev)).to(BF)
+            _lib.check(lib.mmpl_layernorm(_lib.ptr(x), d, _lib.ptr(y), d, rows, d, 1e-6, None, None, 0, S, _lib.ptr(w), _lib.ptr(b), _lib.stream_ptr()))
+            print(f"elem {model} layernorm+mod rows={rows} d={d}  {ms * 1e3:8.1f} us  {gb / ms:6.2f} TB/s  sha {h} affine {sha(y)}", flush=True)
+            qkv0 = torch.randn(rows, 3 * d, device=dev).to(BF)
+            qkv = qkv0.clone()
+            wq = (1 + 0.1 * torch.randn(d, device=dev)).to(BF)
+            wk = (1 + 0.1 * torch.randn(d, device=dev)).to(BF)
+            kc = torch.zeros(nF * S, d, device=dev, dtype=BF)
+            kd = (C.c_void_p * nF)(*[kc[i * S:].data_ptr() for i in range(nF)])
+            fi = (C.c_int * nF)(*range(3, 3 + nF))
+            # v = NULL as in the forward (the QKV GEMM's epilogue writes the V pages)
+            fq = lambda: _lib.check(lib.mmpl_qknorm_rope(eng._h, _lib.ptr(qkv), 3 * d, _lib.ptr(qkv[:, d:]), 3 * d, None, 3 * d, _lib.ptr(wq), _lib.ptr(wk),
+                                                         nF, fi, kd, kd, _lib.stream_ptr()))
+            fq()
+            torch.cuda.synchronize()
+            h = sha(qkv[:, :d], kc)
+            ms = min(timeit(fq, iters), timeit(fq, iters))       # q is normalised in place again and again: same work, values irrelevant
+            gb = 4.0 * rows * d * 2 / 1e9
+            print(f"elem {model} qknorm+rope+kwrite rows={rows} d={d}  {ms * 1e3:8.1f} us  {gb / ms:6.2f} TB/s  sha {h}", flush=True)
+            del qkv, qkv0, kc, x, y
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 5
@@ -175,3 +223,5 @@ if __name__ == "__main__":
         bench_gemm_ref(iters)
     if what == "attnref":
         bench_attn_ref(iters)
+    if what == "elem":
+        bench_elem(iters)

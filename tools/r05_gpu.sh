@@ -89,6 +89,25 @@ for step in "$@"; do
       grep -E "408 forwards|24 forwards|50 steps|i2v|redo counters|passed|failed|rc=|Error" $out/pipetests.log | tail -30 ;;
     chunk13)
       python tools/full_chunk.py --model 1.3B --res 480p > $out/full_chunk_1p3B_480p.json 2>> $out/bench.err; tail -c 500 $out/full_chunk_1p3B_480p.json ;;
+    elem)        # the HBM-bound row passes, two PREBUILT libraries (tools/build/libmmpl_hip_{prev,new}.so) alternating: standalone at the
+                 # stage shapes with hashes of the outputs (tools/bench_kernels.py elem), the kernel tests, then in situ with --profile-all
+      for v in prev new prev new; do
+        cp tools/build/libmmpl_hip_$v.so mmpl_amd/lib/libmmpl_hip.so
+        timeout 600 python tools/bench_kernels.py elem --iters 20 2>&1 | grep "^elem" > $out/elem_$v.log; sed "s/^/lib=$v /" $out/elem_$v.log >> $out/elem_ab.log
+      done
+      for v in prev new; do sed -E 's/ +[0-9.]+ us +[0-9.]+ TB.s//' $out/elem_$v.log > $out/elem_sha_$v.txt; done
+      diff $out/elem_sha_prev.txt $out/elem_sha_new.txt > $out/elem_sha.diff && echo "outputs of the two libraries: identical hashes on every line" >> $out/elem_ab.log || { echo "HASHES DIFFER:" >> $out/elem_ab.log; cat $out/elem_sha.diff >> $out/elem_ab.log; }
+      cp tools/build/libmmpl_hip_new.so mmpl_amd/lib/libmmpl_hip.so
+      timeout 900 python -m pytest tests/test_kernels_gpu.py -q -m gpu -k "layernorm or qknorm" 2>&1 | tail -3 >> $out/elem_ab.log
+      for v in prev new prev new; do
+        cp tools/build/libmmpl_hip_$v.so mmpl_amd/lib/libmmpl_hip.so
+        python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae --profile-all > $out/el_tmp.json 2>> $out/bench.err; line $out/el_tmp.json "14B/720p [lib=$v]" >> $out/elem_ab.log
+        python3 -c "
+import json; r=json.loads(open('$out/el_tmp.json').read().strip().splitlines()[-1]); print('   shares', r.get('kernel_time_share'))" >> $out/elem_ab.log
+        python bench.py --model 1.3B --res 480p --steps 16 --warmup 8 --no-cpu-baseline --no-vae > $out/el_tmp.json 2>> $out/bench.err; line $out/el_tmp.json "1.3B/480p [lib=$v]" >> $out/elem_ab.log
+      done
+      cp tools/build/libmmpl_hip_new.so mmpl_amd/lib/libmmpl_hip.so
+      cat $out/elem_ab.log ;;
     libab)       # two PREBUILT libraries (tools/build/libmmpl_hip_{prev,new}.so) in situ, alternating: 14B / 720p and 1.3B / 480p; then bit-identity of the GEMMs
       for v in prev new prev new; do
         cp tools/build/libmmpl_hip_$v.so mmpl_amd/lib/libmmpl_hip.so
