@@ -98,7 +98,8 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int n_fra
                      int n_slots, const void* cross_k, const void* cross_v, int cross_rows, void* share_out, const void* share_in,
                      void* out, void* workspace, size_t workspace_bytes, mmpl_stream_t stream);
 
-/* attention() seam (wan/modules/attention.py:139-185) over paged K/V.  q/o: row r, head h at base + r*ld + h*128.
+/* attention() seam (wan/modules/attention.py:139-185) over paged K/V.  q/o: row r, head h at base + r*ld + h*128; every base
+ * 16-byte aligned, every leading dimension a multiple of 8 elements (rows are read and written 16 bytes per lane).
  * k_pages/v_pages: host arrays of n_pages dev pointers, each page = page_rows rows of stride ldk/ldv.
  * Softmax does not depend on the order of the keys, the fp32 accumulation does: the 64-rows-per-wave kernel visits the pages in
  * ADDRESS order (back-to-back pages are merged), so a result is bit-reproducible for a given relative placement of the pages.

@@ -230,7 +230,7 @@ def test_gemm_heavy_tailed(lib):
     assert rel_l2(Cc, y) < 2e-3 and bf16_ulp_frac(Cc, y, 2) < 2e-3
 
 
-def _attn_case(lib, Lq, H, S, n_pages, ld_mult=1, seed=0, variant=0, qk_gain=1.0):
+def _attn_case(lib, Lq, H, S, n_pages, ld_mult=1, seed=0, variant=0, qk_gain=1.0, cross=0):
     from mmpl_amd import _lib
     from oracle import wan_dit_ref as W
     torch.manual_seed(seed)
@@ -252,7 +252,7 @@ def _attn_case(lib, Lq, H, S, n_pages, ld_mult=1, seed=0, variant=0, qk_gain=1.0
     kp = (C.c_void_p * n_pages)(*[kc[s * S:].data_ptr() for s in slots])
     vp = (C.c_void_p * n_pages)(*[vc[s * S:].data_ptr() for s in slots])
     _lib.check(lib.mmpl_attn_fwd_variant(_lib.ptr(q), ld_mult * d, _lib.ptr(o), d, kp, vp, d, d, n_pages, S, Lq, H,
-                                         1.0 / math.sqrt(128), None, 0, variant, 0, _sp()))
+                                         1.0 / math.sqrt(128), None, 0, variant, cross, _sp()))
     torch.cuda.synchronize()
     idx = [j for s in slots for j in range(s * S, (s + 1) * S)]
     qq = (q32 if variant == 4 else q)[:, :d].reshape(1, Lq, H, 128).cpu()
@@ -277,6 +277,18 @@ def test_attention_paged(lib, Lq, H, S, n_pages, variant):
     # two-sided bf16 tolerance: kernel and the reference's own bf16 SDPA both within 1e-2 of fp32, and the kernel
     # not worse than 1.5x the reference's bf16 error
     assert e_kernel < 1e-2 and e_kernel < 1.5 * e_ref + 1e-3, (e_kernel, e_ref)
+
+
+@pytest.mark.parametrize("Lq,H,S", [(5000, 40, 65), (5000, 40, 13), (256 * 70, 8, 128), (256 * 9 + 1, 3, 64), (100, 2, 41), (1560 * 7, 12, 65)])
+def test_cross_attention_short_context(lib, Lq, H, S):
+    """Text cross-attention over <= 2 KV tiles (attn_cross_kernel): a block keeps its head's K / V in LDS over a run of query
+    blocks -- several per block at these sizes, a ragged last one -- with the next block's q in flight.  Against fp32, and
+    bit-identical to the lock-step kernel on the same inputs (same tile routine, same order)."""
+    o, ref32, ref16 = _attn_case(lib, Lq, H, S, 1, variant=0, cross=1, seed=S)
+    e_kernel, e_ref = rel_l2(o, ref32), rel_l2(ref16, ref32)
+    assert e_kernel < 1e-2 and e_kernel < 1.5 * e_ref + 1e-3, (e_kernel, e_ref)
+    o_lock, _, _ = _attn_case(lib, Lq, H, S, 1, variant=0, cross=0, seed=S)
+    assert torch.equal(o, o_lock)
 
 
 @pytest.mark.parametrize("variant", [0, 1, 4])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmarks of the two MFMA kernels on the 14B/720p shapes (dev tool).
-    python tools/bench_kernels.py attn|gemm|all|gemmref|attnref|elem [--iters N]"""
+    python tools/bench_kernels.py attn|gemm|all|gemmref|attnref|elem|cross [--iters N]"""
 import ctypes as C
 import math
 import os
@@ -209,6 +209,27 @@ def bench_elem(iters):
             del qkv, qkv0, kc, x, y
 
 
+def bench_cross(iters):
+    """text cross-attention alone (attn_fwd_kernel<1>): Lq query rows x 40 heads against `keys` context rows (valid tokens + the one
+    collapsed padding row), q and o streams of Lq x 5120 bf16 each; time, algorithmic TB/s of q + o, a hash of the output"""
+    import hashlib
+    H, d = 40, 5120
+    for Lq in (25200, 21600, 7200):
+        for keys in (128, 100, 65, 41, 13):
+            torch.manual_seed(keys)
+            q = torch.randn(Lq, d, device=dev).to(BF)
+            k = torch.randn(512, d, device=dev).to(BF)
+            v = torch.randn(512, d, device=dev).to(BF)
+            o = torch.empty_like(q)
+            kp, vp = (C.c_void_p * 1)(k.data_ptr()), (C.c_void_p * 1)(v.data_ptr())
+            fn = lambda: _lib.check(lib.mmpl_attn_fwd_variant(_lib.ptr(q), d, _lib.ptr(o), d, kp, vp, d, d, 1, keys, Lq, H, 1.0 / math.sqrt(128.0),
+                                                              None, 0, 0, 1, _lib.stream_ptr()))
+            ms = min(timeit(fn, iters), timeit(fn, iters))
+            h = hashlib.sha256(o.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:12]
+            print(f"cross Lq={Lq} keys={keys}  {ms * 1e3:8.1f} us  {2.0 * Lq * d * 2 / 1e9 / ms:6.2f} TB/s (q + o)  "
+                  f"{4.0 * Lq * keys * d / ms / 1e9:7.1f} TFLOP/s  sha {h}", flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 5
@@ -225,3 +246,5 @@ if __name__ == "__main__":
         bench_attn_ref(iters)
     if what == "elem":
         bench_elem(iters)
+    if what == "cross":
+        bench_cross(iters)

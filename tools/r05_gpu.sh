@@ -108,6 +108,28 @@ import json; r=json.loads(open('$out/el_tmp.json').read().strip().splitlines()[-
       done
       cp tools/build/libmmpl_hip_new.so mmpl_amd/lib/libmmpl_hip.so
       cat $out/elem_ab.log ;;
+    cross)       # text cross-attention alone (tools/bench_kernels.py cross), two PREBUILT libraries alternating, output hashes; attention tests
+      for v in prev new prev new; do
+        cp tools/build/libmmpl_hip_$v.so mmpl_amd/lib/libmmpl_hip.so
+        timeout 600 python tools/bench_kernels.py cross --iters 20 2>&1 | grep "^cross" > $out/cross_$v.log; sed "s/^/lib=$v /" $out/cross_$v.log >> $out/cross_ab.log
+      done
+      for v in prev new; do sed -E 's/ +[0-9.]+ us .*TFLOP.s//' $out/cross_$v.log > $out/cross_sha_$v.txt; done
+      diff $out/cross_sha_prev.txt $out/cross_sha_new.txt > $out/cross_sha.diff && echo "outputs of the two libraries: identical hashes on every line" >> $out/cross_ab.log || { echo "HASHES DIFFER:" >> $out/cross_ab.log; cat $out/cross_sha.diff >> $out/cross_ab.log; }
+      cp tools/build/libmmpl_hip_new.so mmpl_amd/lib/libmmpl_hip.so
+      timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_dit_forward_gpu.py -q -m gpu -k "attention or attn or cross or clip" 2>&1 | tail -3 >> $out/cross_ab.log
+      cat $out/cross_ab.log ;;
+    crossab)     # attn_cross_kernel in situ, two PREBUILT libraries alternating (prev = the commit before): 14B / 720p --profile-all, 1.3B / 480p
+      cp tools/build/libmmpl_hip_new.so mmpl_amd/lib/libmmpl_hip.so
+      timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_dit_forward_gpu.py -q -m gpu -k "attention or attn or cross or clip" 2>&1 | tail -3 >> $out/crossab.log
+      for v in prev new prev new; do
+        cp tools/build/libmmpl_hip_$v.so mmpl_amd/lib/libmmpl_hip.so
+        python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae --profile-all > $out/cx_tmp.json 2>> $out/bench.err; line $out/cx_tmp.json "14B/720p [lib=$v]" >> $out/crossab.log
+        python3 -c "
+import json; r=json.loads(open('$out/cx_tmp.json').read().strip().splitlines()[-1]); print('   shares', r.get('kernel_time_share'))" >> $out/crossab.log
+        python bench.py --model 1.3B --res 480p --steps 16 --warmup 8 --no-cpu-baseline --no-vae > $out/cx_tmp.json 2>> $out/bench.err; line $out/cx_tmp.json "1.3B/480p [lib=$v]" >> $out/crossab.log
+      done
+      cp tools/build/libmmpl_hip_new.so mmpl_amd/lib/libmmpl_hip.so
+      cat $out/crossab.log ;;
     libab)       # two PREBUILT libraries (tools/build/libmmpl_hip_{prev,new}.so) in situ, alternating: 14B / 720p and 1.3B / 480p; then bit-identity of the GEMMs
       for v in prev new prev new; do
         cp tools/build/libmmpl_hip_$v.so mmpl_amd/lib/libmmpl_hip.so
