@@ -143,6 +143,8 @@ import json; r=json.loads(open('$out/cx_tmp.json').read().strip().splitlines()[-
       cat $out/lib_ab.log $out/lib_ab_gemm_standalone.log ;;
     profiles)    # rocprofv3 kernel stats + PMC passes over bench.py itself (tools/r03_profiles.sh), summaries -> gpurun_out/prof_<tag>/
       bash tools/r03_profiles.sh $tag stats hbm busy > $out/profiles.log 2>&1; tail -6 $out/profiles.log ;;
+    profstats)   # rocprofv3 --kernel-trace --stats over bench.py itself (tools/r03_profiles.sh), summary -> gpurun_out/prof_<tag>/
+      bash tools/r03_profiles.sh $tag stats > $out/profiles.log 2>&1; tail -6 $out/profiles.log ;;
     chunk14)
       python tools/full_chunk.py --model 14B --res 720p > $out/full_chunk_14B_720p.json 2>> $out/bench.err; tail -c 500 $out/full_chunk_14B_720p.json ;;
     others)      # the other BASELINE / reported configurations
