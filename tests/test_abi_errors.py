@@ -52,6 +52,8 @@ def test_kernel_entry_points_reject_bad_shapes():
     kp = (C.c_void_p * 1)(0)
     assert _err(lib.mmpl_attn_fwd(None, 100, None, 128, kp, kp, 128, 128, 1, 64, 64, 1, 0.088, None))      # ldq % 8
     assert _err(lib.mmpl_attn_fwd(None, 128, None, 128, kp, kp, 128, 128, 25, 64, 64, 1, 0.088, None))     # > 24 pages
+    assert _err(lib.mmpl_attn_fwd(None, 128, None, 132, kp, kp, 128, 128, 1, 64, 64, 1, 0.088, None))      # ldo % 8 (rows leave 16 B per lane)
+    assert _err(lib.mmpl_attn_fwd(None, 128, 8, 128, kp, kp, 128, 128, 1, 64, 64, 1, 0.088, None))         # o not 16-byte aligned
     assert _err(lib.mmpl_attn_fwd_variant(None, 128, None, 128, kp, kp, 128, 128, 1, 64, 64, 1, 0.088, None, 0, 9, 0, None))   # unknown kernel variant
     assert _err(lib.mmpl_attn_fwd_variant(None, 128, None, 128, kp, kp, 128, 128, 1, 64, 64, 1, 0.088, None, 0, 2, 0, None))   # the removed ping-pong kernel
     # mmpl_gemm_scratch: the scratch must be there, large enough and 256-byte aligned (checked before anything touches it)
