@@ -93,6 +93,7 @@ const MmplRuntimeConfig& mmpl_config() {
     c.gemm_pf = num("MMPL_GEMM_PF", 2);
     c.gemm_v8 = num("MMPL_GEMM_V8", -1);
     c.vae_no_fuse_norm = flag("MMPL_VAE_NO_FUSE_NORM");
+    c.ln_pipeline_min_rows = num("MMPL_LN_PIPELINE_MIN_ROWS", 16384);
     return c;
   }();
   return cfg;

@@ -4,6 +4,7 @@
 // the reference's bf16 module boundaries round (DESIGN.md "numerics").
 #include "common.h"
 #include "kernels.h"
+#include "mmpl_config.h"
 
 namespace {
 
@@ -462,9 +463,10 @@ hipError_t mmpl_launch_layernorm(const LnArgs& a, hipStream_t s) {
   if (a.rows <= 0) return hipSuccess;
   if (a.d % 8 || a.d > 5120 || a.ldx % 8 || a.ldy % 8) return hipErrorInvalidValue;
   const int nit = (a.d / 8 + 63) / 64;
-  // measured (profiles/r05q_*, r05r_*): the pipeline pays from ~6 row groups per block on rows of >= 6 KB (25 200 x 5120: 131 -> 110 us,
-  // 21 600: 110 -> 98); below that its prologue / tail cost more than the overlap returns (7200 x 5120: 32 vs 35 us; 1536-wide rows: 16 vs 18)
-  if (nit >= 6 && a.rows >= 16384) {
+  // measured (profiles/r05q_*, r05r_*, r05x_*): the pipeline pays from ~6 row groups per block on rows of >= 6 KB (25 200 x 5120: 131 -> 110 us,
+  // 21 600: 110 -> 98); below that its prologue / tail cost more than the overlap returns (10 920 x 5120: 44 vs 46 us, 9360: 40 vs 45,
+  // 7200: 33 vs 35; 1536-wide rows: 16 vs 18).  MMPL_LN_PIPELINE_MIN_ROWS moves the threshold (mmpl_config.h).
+  if (nit >= 6 && a.rows >= mmpl_config().ln_pipeline_min_rows) {
     const bool full = a.d == 512 * nit && a.rows % 4 == 0 && (a.w || a.rows_per_frame % 4 == 0);
     DISPATCH_PIPELINED(nit, layernorm_pipelined_kernel, a, a.rows, 1, s, full);
   } else {

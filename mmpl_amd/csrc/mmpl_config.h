@@ -15,6 +15,7 @@
 //   MMPL_GEMM_NO_SUBTILE=1       short-K GEMMs without the 128 x 128 sub-tile launch for the partial last round of tiles
 //   MMPL_GEMM_V8=0|1             large GEMMs never / always on gemm_bf16_v8_kernel (default: the launcher's per-shape choice)
 //   MMPL_VAE_NO_FUSE_NORM=1      RMS_norm + SiLU of the 96-channel layers as its own pass instead of the producing conv's epilogue
+//   MMPL_LN_PIPELINE_MIN_ROWS=n  rows from which LayerNorm takes the pipelined kernel (default 16384; 0 = always, a huge n = never)
 #pragma once
 
 struct MmplRuntimeConfig {
@@ -24,5 +25,6 @@ struct MmplRuntimeConfig {
   int gemm_pf;         // k-tiles
   int gemm_v8;         // -1 = launcher's choice, 0 / 1 = never / always the one-wave-per-SIMD kernel for the main launch
   bool vae_no_fuse_norm;
+  int ln_pipeline_min_rows;
 };
 const MmplRuntimeConfig& mmpl_config();

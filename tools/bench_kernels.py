@@ -173,7 +173,8 @@ def bench_elem(iters):
             h.update(t.contiguous().view(torch.int16).cpu().numpy().tobytes())
         return h.hexdigest()[:12]
 
-    for model, d, H, lat, S, frames_list in (("14B/720p", 5120, 40, (90, 160), 3600, (7, 6, 2)), ("1.3B/480p", 1536, 12, (60, 104), 1560, (7, 6, 2))):
+    for model, d, H, lat, S, frames_list in (("14B/720p", 5120, 40, (90, 160), 3600, (7, 6, 2)), ("14B/480p", 5120, 40, (60, 104), 1560, (7, 6, 2)),
+                                             ("1.3B/480p", 1536, 12, (60, 104), 1560, (7, 6, 2))):
         eng = DitEngine(dict(dim=d, ffn_dim=256, num_heads=H, num_layers=1, text_dim=64), lat[0], lat[1], dev)
         for nF in frames_list:
             rows = nF * S
