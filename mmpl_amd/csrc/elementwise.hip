@@ -1,7 +1,8 @@
 // HBM-bound kernels of the Wan DiT forward: LayerNorm+modulate, full-dim QK RMSNorm + 3-axis RoPE + KV page
 // write, patchify / unpatchify, timestep sinusoid, modulation prep, CFG + UniPC step.
-// All of them move 16 B per lane, one wave per token row, fp32 statistics, and round to bf16 exactly where
-// the reference's bf16 module boundaries round (DESIGN.md "numerics").
+// All of them move 16 B per lane, a wave works on one token row at a time (the two big ones walk a range of rows with the next
+// row's loads in flight), fp32 statistics, and round to bf16 exactly where the reference's bf16 module boundaries round
+// (DESIGN.md "numerics"); every fp32 expression whose rounding matters is written with explicit fmaf under contract(off).
 #include "common.h"
 #include "kernels.h"
 #include "mmpl_config.h"
