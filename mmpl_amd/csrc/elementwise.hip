@@ -23,6 +23,7 @@ MMPL_DEV uint4 pack8(const float (&f)[8]) {
 // one wave per row; the row lives in registers (NIT chunks of 8 per lane) -> exact two-pass mean / variance.
 template <int NIT>
 __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
+#pragma clang fp contract(off)                                    // one fma, written out (the affine form): the same bits as layernorm_pipelined_kernel
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.rows) return;
   const int lane = threadIdx.x & 63;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
       unpack8(*reinterpret_cast<const uint4*>(a.w + ch * 8), w);
       unpack8(*reinterpret_cast<const uint4*>(a.b + ch * 8), b);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (v[it][j] - mean) * rstd * w[j] + b[j];
+      for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf((v[it][j] - mean) * rstd, w[j], b[j]);
     } else {
       float sc[8], sh[8];
       unpack8(*reinterpret_cast<const uint4*>(a.scale + (size_t)frame * a.mod_frame_stride + ch * 8), sc);
