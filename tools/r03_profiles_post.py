@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Post-processes what tools/r03_profiles.sh collected: python3 tools/r03_profiles_post.py <dir> <tag>
-   -> <dir>/<tag>_kernel_stats.csv, <dir>/<tag>_pmc_attention_hbm.json, <dir>/<tag>_pmc_mfma_busy.md"""
+   -> <dir>/<tag>_kernel_stats.csv, <dir>/<tag>_pmc_attention_hbm.json, <dir>/<tag>_pmc_hbm_per_kernel.md, <dir>/<tag>_pmc_mfma_busy.md"""
 import collections
 import csv
 import glob
@@ -62,6 +62,35 @@ if len(vals) == 2:
     # bench.py reads roofline.traffic from the file THIS names (copy both into profiles/): no sorted glob
     json.dump({"attention_traffic_file": f"{tag}_pmc_attention_hbm.json", "written_by": "tools/r03_profiles_post.py"},
               open(os.path.join(d, "PMC_TRAFFIC.json"), "w"))
+
+# ---- HBM traffic per launch of EVERY kernel (the same two passes): what the memory-bound passes really move
+per = {}
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    fs = glob.glob(os.path.join(d, f"hbm_{ctr}", "**", "*counter_collection.csv"), recursive=True)
+    if not fs:
+        continue
+    tot, seen = collections.defaultdict(float), collections.defaultdict(set)
+    for r in csv.DictReader(open(fs[0])):
+        if r["Counter_Name"] != ctr:
+            continue
+        k = short(r["Kernel_Name"])
+        tot[k] += float(r["Counter_Value"])
+        seen[k].add(r["Dispatch_Id"])
+    per[ctr] = {k: (tot[k], len(seen[k])) for k in tot}
+if len(per) == 2:
+    lines = [f"# {tag} PMC: HBM traffic per launch, every kernel of 4 eager denoise steps of `bench.py` (14B / 720p rotation s0..s3)", "",
+             "`rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes); bytes = KiB x 1024, FETCH_SIZE x 2 on gfx950",
+             "(MI355X_MICROARCH.md, HBM section).  Mean over the launches of the rotation (stage shapes of 7200 / 25 200 / 21 600 / 21 600 query rows,",
+             "mean 18 900): LayerNorm algorithmic = 2 x rows x 5120 x 2 B = 0.387 GB, q / k norm + RoPE + K write = 4 x ... = 0.774 GB (the",
+             "cross-attention's q norm, same kernel: 0.387 GB), text cross-attention q + o = 0.387 GB.", "",
+             "| kernel | launches | read GB / launch | written GB / launch | total GB / launch |", "|---|---|---|---|---|"]
+    ks = sorted(per["FETCH_SIZE"], key=lambda k: -(per["FETCH_SIZE"][k][0] * 2 + per["WRITE_SIZE"].get(k, (0, 1))[0]))
+    for k in ks[:24]:
+        f, n = per["FETCH_SIZE"][k]
+        w, _ = per["WRITE_SIZE"].get(k, (0.0, n))
+        rd, wr = f * 1024 * 2 / n / 1e9, w * 1024 / n / 1e9
+        lines.append(f"| `{k[:80]}` | {n} | {rd:.3f} | {wr:.3f} | {rd + wr:.3f} |")
+    open(os.path.join(d, f"{tag}_pmc_hbm_per_kernel.md"), "w").write("\n".join(lines) + "\n")
 
 # ---- MFMA busy per kernel
 fs = glob.glob(os.path.join(d, "busy", "**", "*counter_collection.csv"), recursive=True)

@@ -145,6 +145,8 @@ import json; r=json.loads(open('$out/cx_tmp.json').read().strip().splitlines()[-
       bash tools/r03_profiles.sh $tag stats hbm busy > $out/profiles.log 2>&1; tail -6 $out/profiles.log ;;
     profstats)   # rocprofv3 --kernel-trace --stats over bench.py itself (tools/r03_profiles.sh), summary -> gpurun_out/prof_<tag>/
       bash tools/r03_profiles.sh $tag stats > $out/profiles.log 2>&1; tail -6 $out/profiles.log ;;
+    profhbm)     # FETCH_SIZE / WRITE_SIZE PMC passes over bench.py itself (tools/r03_profiles.sh): attention op + per-kernel table
+      bash tools/r03_profiles.sh $tag hbm > $out/profiles_hbm.log 2>&1; tail -6 $out/profiles_hbm.log ;;
     chunk14)
       python tools/full_chunk.py --model 14B --res 720p > $out/full_chunk_14B_720p.json 2>> $out/bench.err; tail -c 500 $out/full_chunk_14B_720p.json ;;
     others)      # the other BASELINE / reported configurations
