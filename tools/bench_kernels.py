@@ -214,9 +214,9 @@ def bench_cross(iters):
     """text cross-attention alone (attn_fwd_kernel<1>): Lq query rows x 40 heads against `keys` context rows (valid tokens + the one
     collapsed padding row), q and o streams of Lq x 5120 bf16 each; time, algorithmic TB/s of q + o, a hash of the output"""
     import hashlib
-    H, d = 40, 5120
-    for Lq in (25200, 21600, 7200):
-        for keys in (128, 100, 65, 41, 13):
+    for H, d, Lq, keys in [(40, 5120, Lq, keys) for Lq in (25200, 21600, 7200) for keys in (128, 100, 65, 41, 13)] + \
+                          [(12, 1536, Lq, keys) for Lq in (10920, 9360, 3120) for keys in (65, 41)]:
+        if True:
             torch.manual_seed(keys)
             q = torch.randn(Lq, d, device=dev).to(BF)
             k = torch.randn(512, d, device=dev).to(BF)
@@ -227,7 +227,7 @@ def bench_cross(iters):
                                                               None, 0, 0, 1, _lib.stream_ptr()))
             ms = min(timeit(fn, iters), timeit(fn, iters))
             h = hashlib.sha256(o.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:12]
-            print(f"cross Lq={Lq} keys={keys}  {ms * 1e3:8.1f} us  {2.0 * Lq * d * 2 / 1e9 / ms:6.2f} TB/s (q + o)  "
+            print(f"cross H={H} Lq={Lq} keys={keys}  {ms * 1e3:8.1f} us  {2.0 * Lq * d * 2 / 1e9 / ms:6.2f} TB/s (q + o)  "
                   f"{4.0 * Lq * keys * d / ms / 1e9:7.1f} TFLOP/s  sha {h}", flush=True)
 
 
