@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
 // registers (NIT x 16 B per lane) and is unpacked once per pass; q rows and k rows go to different blocks (grid.y).  vmcnt is
 // in order on gfx9, so nothing the current row needs may be loaded from global memory behind that prefetch: the per-column
 // vectors (modulation / affine / gain) are staged in LDS once per block (and per frame), RoPE factors ride with the prefetch.
-// Same arithmetic, rounding for rounding (hashes of the outputs: profiles/r05r_*): 4.7 / 4.6 TB/s.
+// Same arithmetic, rounding for rounding (hashes of the outputs: profiles/r05r_*): 4.4-4.7 / 4.6 TB/s.  (The q / k pass
+// of round 4 -- q, then k, in one wave, rows unpacked to floats -- is gone; its record is profiles/r05p_*.)
 MMPL_DEV void keep_packed(uint4& u) { asm volatile("" : "+v"(u.x), "+v"(u.y), "+v"(u.z), "+v"(u.w)); }
 
 // FULL: d == 512 NIT and rows % 4 == 0 (every model shape): no per-chunk / per-row predicate anywhere, so the number of
