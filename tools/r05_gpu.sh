@@ -130,6 +130,16 @@ import json; r=json.loads(open('$out/cx_tmp.json').read().strip().splitlines()[-
       done
       cp tools/build/libmmpl_hip_new.so mmpl_amd/lib/libmmpl_hip.so
       cat $out/crossab.log ;;
+    insitu)      # two PREBUILT libraries alternating in situ: 14B / 720p --profile-all (with shares) and 1.3B / 480p
+      for v in prev new prev new; do
+        cp tools/build/libmmpl_hip_$v.so mmpl_amd/lib/libmmpl_hip.so
+        python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-vae --profile-all > $out/is_tmp.json 2>> $out/bench.err; line $out/is_tmp.json "14B/720p [lib=$v]" >> $out/insitu_ab.log
+        python3 -c "
+import json; r=json.loads(open('$out/is_tmp.json').read().strip().splitlines()[-1]); print('   shares', r.get('kernel_time_share'))" >> $out/insitu_ab.log
+        python bench.py --model 1.3B --res 480p --steps 16 --warmup 8 --no-cpu-baseline --no-vae > $out/is_tmp.json 2>> $out/bench.err; line $out/is_tmp.json "1.3B/480p [lib=$v]" >> $out/insitu_ab.log
+      done
+      cp tools/build/libmmpl_hip_new.so mmpl_amd/lib/libmmpl_hip.so
+      cat $out/insitu_ab.log ;;
     libab)       # two PREBUILT libraries (tools/build/libmmpl_hip_{prev,new}.so) in situ, alternating: 14B / 720p and 1.3B / 480p; then bit-identity of the GEMMs
       for v in prev new prev new; do
         cp tools/build/libmmpl_hip_$v.so mmpl_amd/lib/libmmpl_hip.so
