@@ -44,6 +44,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "dev_knobs.h"
 #include "kernels.h"
 #include "w64_util.h"
 
@@ -52,25 +53,16 @@ namespace {
 constexpr int QB = 256, KVB = 64, TILE = KVB * 256, RING = 4;         // K ring [0, 64 KiB), V ring [64 KiB, 128 KiB)
 constexpr int W64_SMEM = 2 * RING * TILE + 64;     // + the block's redo flag
 constexpr float BOUND_GEN = 1073741824.f;                              // 2^30: a GENERAL tile's partial row sums
-#ifndef W64_LMIN_EXP
-#define W64_LMIN_EXP 100
-#endif
-#ifndef W64_LMAX_EXP
-#define W64_LMAX_EXP 100
-#endif
 constexpr float pow2f(int e) { return e == 0 ? 1.f : (e > 0 ? 2.f * pow2f(e - 1) : 0.5f * pow2f(e + 1)); }
+// Build parameters and timing ablations: dev_knobs.h.  A product build has the shipped constants and W64_ABL == 0, so every
+// `if constexpr (ABL(bits))` below is dead code the compiler drops.
+#define ABL(bits) ((W64_ABL & (bits)) != 0)
 // 2^-100 <= l <= 2^100: a FAST pass's final row sums.  The window is where the fp32 exponent range puts it: above, O <= l |v| must stay finite;
 // below, every p under 2^-126 is flushed to zero -- N keys lose at most N 2^-126, which is <= 2^-9.8 of l (under a bf16 ulp of the output)
 // for N = 75 600 keys exactly when l >= 2^-100.  Lowering the bound to 2^-124 cut the heavy-tail x8 redo rate from 26.7 to 18.1 % of the
 // blocks (profiles/r05c_attn_fast_window_offsets.log) but voids that guarantee; moving the offset only trades one side for the other.
 constexpr float FAST_L_MIN = pow2f(-W64_LMIN_EXP), FAST_L_MAX = pow2f(W64_LMAX_EXP);
-#ifndef W64_REF_OFFSET
-#define W64_REF_OFFSET 64
-#endif
 constexpr float FAST_REF_OFFSET = W64_REF_OFFSET;   // FAST pass: m_ref = (largest score of the block's first FAST_REF_TILES KV tiles) + this
-#ifndef W64_REF_TILES
-#define W64_REF_TILES 4
-#endif
 constexpr int FAST_REF_TILES = W64_REF_TILES;  // 1 .. 4 (= RING: the tiles the prologue fetches before the pipeline starts)
 
 using w64::sfor;
@@ -78,14 +70,6 @@ using w64::sfor;
 
 constexpr int AO = 0, AQ = 128, AV = 192;      // accumulator-file map
 
-// Timing ablations for tools/w64_sweep.sh (results are garbage): -DW64_ABL=<bits>  1 no LDS-DMA in the loop, 2 no softmax,
-// 4 no fragment reads, 8 no barrier / waits, 16 leave per-wave loop cycle counts in o (tools/attn_dev.py cycles), 32 / 64 / 128
-// no exp / row-sum adds / bf16 packs, 256 every V fragment by ONE ds_read_b128 in K's conflict-free lane pattern instead of two
-// ds_read_b64_tr_b16 (what a V tile stored pre-transposed would cost: same LDS bytes, half the V read instructions).  0 in every
-// shipped build.
-#ifndef W64_ABL
-#define W64_ABL 0
-#endif
 // All state of a wave.  Passed by reference through always-inlined members, so every field ends up in a register (VGPR or,
 // when provably wave-uniform, SGPR); arrays are only ever indexed with compile-time constants.
 struct Ctx {
@@ -114,7 +98,6 @@ struct Ctx {
   int first[2];                                // GENERAL pass: stream has not finished its first tile yet
   int prow, drow, dchunk;
   uint32_t wave_slot;                          // this wave's first piece within a ring slot
-  unsigned long long ticks;                    // W64_ABL & 16: shader cycles of the pass's steady loop
 
   // ---------------------------------------------------------------- MFMAs
   template <int X, int G> MMPL_DEV void mfma_qk() {      // S_X[h] (+)= K frag G . Q_X[chunk]
@@ -130,15 +113,14 @@ struct Ctx {
                  "v"(P[X][ks]));
   }
   // ---------------------------------------------------------------- LDS fragment reads
-  MMPL_DEV void addr_k() { if constexpr (W64_ABL & 4) return; asm volatile("v_add_u32 %0, %1, %2" : "=v"(kaddr) : "s"(rk), "v"(kbase)); }
+  MMPL_DEV void addr_k() { if constexpr (ABL(4)) return; asm volatile("v_add_u32 %0, %1, %2" : "=v"(kaddr) : "s"(rk), "v"(kbase)); }
   MMPL_DEV void addr_v() {
-    if constexpr (W64_ABL & 4) return;
-    if constexpr (W64_ABL & 256) { asm volatile("v_add_u32 %0, %1, %2" : "=v"(vaddr[0]) : "s"(rv), "v"(kbase + RING * TILE)); return; }
+    if constexpr (ABL(4)) return;
     asm volatile("v_add_u32 %0, %4, %5\n\tv_xor_b32 %1, 64, %0\n\tv_xor_b32 %2, 0x80, %0\n\tv_xor_b32 %3, 0xc0, %0"
                  : "=&v"(vaddr[0]), "=&v"(vaddr[1]), "=&v"(vaddr[2]), "=&v"(vaddr[3]) : "s"(rv), "v"(vbase));
   }
   template <int G> MMPL_DEV void lds_k() {               // fragment G = (chunk, half); the chunk enters the address by XOR
-    if constexpr (W64_ABL & 4) return;
+    if constexpr (ABL(4)) return;
     constexpr int off = (G & 1) * 32 * 256, cs = G >> 1;
     if constexpr ((G & 1) == 0 && G > 0)
       asm volatile("v_xor_b32 %1, %2, %1\n\tds_read_b128 %0, %1 offset:%c3" : "=v"(kf[G]), "+v"(kaddr) : "i"((32 * cs) ^ (32 * (cs - 1))), "i"(off));
@@ -146,25 +128,17 @@ struct Ctx {
       asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(kf[G]) : "v"(kaddr), "i"(off));
   }
   template <int G> MMPL_DEV void lds_v() {               // fragment G = (ks, nb) -> a[192 + 4G ..]
-    if constexpr (W64_ABL & 4) return;
-    if constexpr (W64_ABL & 256) {                          // mock: lds_k's address walk on the V ring, straight into the accumulator file
-      constexpr int va_ = AV + 4 * G, off_ = (G & 1) * 32 * 256, cs = G >> 1;
-      if constexpr ((G & 1) == 0 && G > 0)
-        asm volatile("v_xor_b32 %0, %1, %0\n\tds_read_b128 a[%c2:%c3], %0 offset:%c4" : "+v"(vaddr[0]) : "i"((32 * cs) ^ (32 * (cs - 1))), "i"(va_), "i"(va_ + 3), "i"(off_));
-      else
-        asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" ::"v"(vaddr[0]), "i"(va_), "i"(va_ + 3), "i"(off_));
-      return;
-    }
+    if constexpr (ABL(4)) return;
     constexpr int va = AV + 4 * G, off = (G >> 2) * 16 * 256;
     asm volatile("ds_read_b64_tr_b16 a[%c1:%c2], %0 offset:%c3\n\tds_read_b64_tr_b16 a[%c4:%c5], %0 offset:%c6" ::"v"(vaddr[G & 3]),
                  "i"(va), "i"(va + 1), "i"(off), "i"(va + 2), "i"(va + 3), "i"(off + 8 * 256));
   }
-  template <int N> MMPL_DEV void wait_lgkm() { if constexpr (W64_ABL & 8) return; asm volatile("s_waitcnt lgkmcnt(%c0)" ::"i"(N) : "memory"); }
-  MMPL_DEV void wait_lgkm0() { if constexpr (W64_ABL & 8) return; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+  template <int N> MMPL_DEV void wait_lgkm() { if constexpr (ABL(8)) return; asm volatile("s_waitcnt lgkmcnt(%c0)" ::"i"(N) : "memory"); }
+  MMPL_DEV void wait_lgkm0() { if constexpr (ABL(8)) return; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
   // K(j+1) and V(j) (DMA event j-3) have landed when at most the 16 pieces of events j-1 and j-2 are outstanding -- two whole
   // tile times of latency cover (with one, vmcnt(8), the wait costs ~150 cycles per tile: measured); all of this wave's
   // fragment reads of the slots event j is about to overwrite are complete (lgkmcnt 0)
-  MMPL_DEV void barrier() { if constexpr (W64_ABL & 8) return; asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+  MMPL_DEV void barrier() { if constexpr (ABL(8)) return; asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
   // ---------------------------------------------------------------- LDS-DMA (event j = { K(j+4), V(j+3) })
   // A piece = 4 rows x 256 B = one buffer_load_dwordx4 ... lds.  Wave w moves pieces 4w..4w+3 of a tile; M0 (the LDS
@@ -178,14 +152,14 @@ struct Ctx {
   // scalar write of the offset / descriptor registers (the cursor advance, which hipcc may place right before this asm
   // without knowing what is inside it) and the VMEM instruction that reads them.
   template <int K> MMPL_DEV void dma_k() {
-    if constexpr (W64_ABL & 1) return;
+    if constexpr (ABL(1)) return;
     if constexpr (K == 0)
       asm volatile("s_mov_b32 m0, %3\n\ts_nop 3\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(dko[0]), "s"(ksrd), "s"(ksoff), "s"(kslot) : "memory");
     else
       asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:%c3 lds" ::"v"(dko[K]), "s"(ksrd), "s"(ksoff), "i"(1024 * K) : "memory");
   }
   template <int K> MMPL_DEV void dma_v() {
-    if constexpr (W64_ABL & 1) return;
+    if constexpr (ABL(1)) return;
     if constexpr (K == 0)
       asm volatile("s_mov_b32 m0, %3\n\ts_nop 3\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(dvo[0]), "s"(vsrd), "s"(vsoff), "s"(vslot) : "memory");
     else
@@ -287,7 +261,7 @@ struct Ctx {
   // ---------------------------------------------------------------- softmax streams (placement: attn_w64_sched.inc)
   // pair q of stream X: registers e, e+1 of S_X[h]; packed into word wd of P_X[ks]
   template <int MODE, int X, int Q, int EL> MMPL_DEV void sm_e() {
-    if constexpr (W64_ABL & (2 | 32)) return;
+    if constexpr (ABL(2 | 32)) return;
     constexpr int h = Q >> 3, e = (Q & 7) * 2 + EL;
     if constexpr (MODE == 0)
       asm volatile("v_exp_f32 %0, %1" : "=v"(t[X][Q & 1][EL]) : "v"(S[X][h][e]));
@@ -297,17 +271,17 @@ struct Ctx {
   template <int MODE, int X, int Q> MMPL_DEV void sm_e0() { sm_e<MODE, X, Q, 0>(); }
   template <int MODE, int X, int Q> MMPL_DEV void sm_e1() { sm_e<MODE, X, Q, 1>(); }
   template <int MODE, int X, int Q> MMPL_DEV void sm_a0() {
-    if constexpr (W64_ABL & (2 | 64)) return;
+    if constexpr (ABL(2 | 64)) return;
     if constexpr (Q == 0 && MODE == 1) la[X] = t[X][0][0];
     else asm volatile("v_add_f32 %0, %0, %1" : "+v"(la[X]) : "v"(t[X][Q & 1][0]));
   }
   template <int MODE, int X, int Q> MMPL_DEV void sm_a1() {
-    if constexpr (W64_ABL & (2 | 64)) return;
+    if constexpr (ABL(2 | 64)) return;
     if constexpr (Q == 0 && MODE == 1) lb[X] = t[X][0][1];
     else asm volatile("v_add_f32 %0, %0, %1" : "+v"(lb[X]) : "v"(t[X][Q & 1][1]));
   }
   template <int MODE, int X, int Q> MMPL_DEV void sm_c() {
-    if constexpr (W64_ABL & (2 | 128)) return;
+    if constexpr (ABL(2 | 128)) return;
     constexpr int ks = Q >> 2, wd = Q & 3;
     asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(P[X][ks][wd]) : "v"(t[X][Q & 1][0]), "v"(t[X][Q & 1][1]));
   }
@@ -354,7 +328,7 @@ struct Ctx {
     return mx;
   }
   template <int MODE, int X> MMPL_DEV void finish() {
-    if constexpr (MODE == 0 || (W64_ABL & (2 | 4 | 32 | 64 | 128))) return;     // FAST: la / lb run on; timing ablations: no slow path
+    if constexpr (MODE == 0 || ABL(2 | 4 | 32 | 64 | 128)) return;     // FAST: la / lb run on; timing ablations: no slow path
     float lt = la[X] + lb[X];
     if (__builtin_expect(first[X] || __any(!(lt <= BOUND_GEN)), 0)) lt = slow<X>(lt);
     l[X] += lt;
@@ -398,7 +372,7 @@ template <int MODE> MMPL_DEV void w64_pass(Ctx& k) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   k.plan(0);
-  if constexpr (MODE == 0 && W64_ABL == 0) {
+  if constexpr (MODE == 0 && !ABL(~0)) {
     // FAST pass reference (header): the scores of KV tile 0 for both query blocks, their largest per lane (= two query rows) + offset
     // becomes m_ref; it enters every later score through the C operand of the tile's first MFMA, so the pipeline below is untouched.
     sfor<16>([&k](auto gi) { k.template mfma_qk<0, decltype(gi)::value>(); });
@@ -433,8 +407,6 @@ template <int MODE> MMPL_DEV void w64_pass(Ctx& k) {
   }
   w64_phase_a<MODE, true, false, true, false>(k);
   w64_phase_b<MODE, true, false, true, false>(k);
-  [[maybe_unused]] unsigned long long tick0 = 0;
-  if constexpr (W64_ABL & 16) tick0 = __builtin_readcyclecounter();
   // runs of identical, branch-free iterations; whatever happens once per page is decided in between (Ctx::plan)
 #pragma unroll 1
   for (int j = 1; j < T;) {
@@ -446,7 +418,6 @@ template <int MODE> MMPL_DEV void w64_pass(Ctx& k) {
       w64_phase_b<MODE, true, true, true, true>(k);
     }
   }
-  if constexpr (W64_ABL & 16) k.ticks = __builtin_readcyclecounter() - tick0;
   w64_phase_a<MODE, false, true, false, true>(k);
   w64_phase_b<MODE, false, true, false, true>(k);
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -542,7 +513,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const float l_tot = k.l[X] + __shfl_xor(k.l[X], 32, 64);
       bad |= !(l_tot >= FAST_L_MIN && l_tot <= FAST_L_MAX);
     }
-    if constexpr (W64_ABL != 0) bad = false;
+    if constexpr (ABL(~0)) bad = false;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // the parked cursors' last re-fetches
     if (__any(bad) && lane == 0) *redo = 1;
     __syncthreads();
@@ -582,14 +553,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     } else {
       const float inv = 1.0f / l_tot;
       const int q_out = qb * QB + rr;
-      if constexpr (W64_ABL & 16) {
-        // timing build (dev): instead of O, each wave leaves { shader cycles of its steady loops, tiles in them }
-        if (X == 0 && lane == 0) {
-          float* tp = reinterpret_cast<float*>(a.o) + (blockIdx.x * 4 + wave) * 2;
-          tp[0] = (float)k.ticks;
-          tp[1] = (float)(T - 1);
-        }
-      } else if (q_out < a.Lq) {
+      if (q_out < a.Lq) {
         bf16_t* op = a.o + (size_t)q_out * a.ldo + head * 128 + 4 * hi;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)

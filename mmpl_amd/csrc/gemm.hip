@@ -11,9 +11,19 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "dev_knobs.h"
 #include "kernels.h"
 #include "w64_util.h"
 #include "mmpl_config.h"
+
+// per-phase shader-cycle counters of the large-problem kernels: development builds with -DGEMM6_TIMING=1 only (dev_knobs.h)
+#ifdef MMPL_DEV_ABLATIONS
+#define GEMM_DEV_TICKS [[maybe_unused]] unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0
+#define GEMM_DEV_TICK(x) do { if constexpr (GEMM6_TIMING) x = __builtin_readcyclecounter(); } while (0)
+#else
+#define GEMM_DEV_TICKS do { } while (0)
+#define GEMM_DEV_TICK(x) do { } while (0)
+#endif
 
 namespace {
 using w64::sfor;
@@ -353,14 +363,7 @@ MMPL_DEV int swz64(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
 // at 8192^3).  With the DMA ops removed the same kernel runs at 1450-1470: the LDS-DMA issue stalls (~100 cycles per
 // op) are the remaining cost.  A BK = 32 / 4-deep-ring variant in which both groups issue their own DMA ops inside
 // their R segments was slower (twice the barriers: 1040-1150).
-// dev (cache-policy experiments on the operand streams, profiles/r05*_gemm_policy*.log): -DGEMM_POLICY_A=n / -DGEMM_POLICY_W=n: modifier
-// of the LDS-DMA loads of the activation / weight operand in the large-problem kernels: 0 none (every shipped build), 1 nt, 2 sc1, 3 sc0 sc1
-#ifndef GEMM_POLICY_A
-#define GEMM_POLICY_A 0
-#endif
-#ifndef GEMM_POLICY_W
-#define GEMM_POLICY_W 0
-#endif
+// cache-policy modifier of the operand streams' LDS-DMA loads (dev_knobs.h GEMM_POLICY_A / _W; "" in every shipped build)
 #define GEMM_POL_STR_0 ""
 #define GEMM_POL_STR_1 " nt"
 #define GEMM_POL_STR_2 " sc1"
@@ -382,17 +385,6 @@ MMPL_DEV void glds16s_w(const void* base, uint32_t voff, char* lds) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" GEMM_POL_W ::"v"(voff), "s"(base), "s"(dst) : "memory");
 }
 
-#ifndef GEMM6_ABL
-#define GEMM6_ABL 0         // dev ablations (results are garbage): 1 = every block's LDS-DMA reads operand tile (0, 0): same instruction
-#endif                      // stream and LDS traffic, every fetch an L2 hit -> what the loop costs without fabric / HBM latency;
-                            // 2 = no epilogue at all (what a perfectly overlapped epilogue would leave); 4 = no LDS-DMA in the k loop;
-                            // 8 = the whole staged epilogue except its global stores
-#ifndef GEMM6_STORE
-#define GEMM6_STORE 1       // cache policy of the staged epilogue's C stores: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1 (write-through, no L2 allocate)
-#endif
-#ifndef GEMM6_RESLD
-#define GEMM6_RESLD 0       // residual loads of the staged epilogue: 0 plain, 1 nt
-#endif
 MMPL_DEV void store16_c(void* p, const uint4& v) {
   const u32x4 w = {v.x, v.y, v.z, v.w};
 #if GEMM6_STORE == 1
@@ -563,9 +555,6 @@ MMPL_DEV void load16x8_sys(const f32x4* p, f32x4 (&v)[8]) {      // rows p, p + 
                : "memory");
 }
 
-#ifndef GEMM6_TIMING
-#define GEMM6_TIMING 0      // dev: 1 = every wave leaves { prologue, k loop, epilogue } shader cycles over the output (tools/bench_kernels.py gemmphases)
-#endif
 // SPLITK = true: the second launch of a GEMM whose tile count leaves a partial last round of one-tile-per-CU (launch_v6).  The main
 // launch stops at the last full round of every XCD's list; here each leftover tile is computed by `splitk_s` blocks over 1/s of the
 // k-tiles each.  Every part leaves its fp32 accumulators in splitk_ws (lane-private layout, fully coalesced) and draws a ticket of
@@ -574,8 +563,8 @@ MMPL_DEV void load16x8_sys(const f32x4* p, f32x4 (&v)[8]) {      // rows p, p + 
 template <int EPI, bool SPLITK = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_v6_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  [[maybe_unused]] unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
-  if constexpr (GEMM6_TIMING) tk0 = __builtin_readcyclecounter();
+  GEMM_DEV_TICKS;
+  GEMM_DEV_TICK(tk0);
   const int tiles_m = (g.M + BM3 - 1) / BM3, tiles_n = (g.N + BN3 - 1) / BN3;
   const int nwg = tiles_m * tiles_n;
   // Tile order: every XCD owns a list of tiles in grouped-M order (below), so that the blocks sharing one L2 work on neighbouring
@@ -689,7 +678,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   __builtin_amdgcn_s_barrier();
   if (grp == 1) __builtin_amdgcn_s_barrier();          // group B runs half a tile late
-  if constexpr (GEMM6_TIMING) tk1 = __builtin_readcyclecounter();
+  GEMM_DEV_TICK(tk1);
 
   for (int t = 0; t < nt; ++t) {
     // =========================== R_t
@@ -749,7 +738,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // LDS staging, stores -- while group B is still multiplying, and the tile's HBM burst comes in two halves.
     if (grp == 0 || t + 1 < nt) __builtin_amdgcn_s_barrier();
   }
-  if constexpr (GEMM6_TIMING) tk2 = __builtin_readcyclecounter();
+  GEMM_DEV_TICK(tk2);
   if constexpr (SPLITK) {
     // partial of this k range: register r of lane l of wave w at ((part slot * 8 + w) * 32 + r) * 64 + l (16 bytes each)
     const size_t part_floats = (size_t)8 * 32 * 64 * 4;
@@ -795,6 +784,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     gemm_epilogue<EPI>(g, acc[0], m0 + 128 * wm, n0 + 64 * wn, frow, fchunk);
     gemm_epilogue<EPI>(g, acc[1], m0 + 128 * wm + 64, n0 + 64 * wn, frow, fchunk);
   }
+#ifdef MMPL_DEV_ABLATIONS
   if constexpr (GEMM6_TIMING) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     tk3 = __builtin_readcyclecounter();
@@ -807,6 +797,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       tp[3] = (float)(2 * nt);                                // in 32-wide k stages
     }
   }
+#endif
   if (g.pf_dist > 0 && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // prefetch DMAs target this block's LDS
   if (!persistent) return;
   __syncthreads();                 // the ring (and s_ticket) are free again: every wave is done with its epilogue's staging
@@ -923,9 +914,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   else gemm128_tile<EPI>(g, smem, m0, n0);
 }
 
-#ifndef GEMM8_ABL
-#define GEMM8_ABL 0         // dev ablations of the v8 loop (results are garbage): 1 no LDS-DMA, 4 no fragment reads, 8 no barriers / waits
-#endif
 // ---------------------------------------------------------------------------------------------------------------
 // v8 "w128": the same 256x256x64 block tile, 2-stage LDS-DMA ring, LDS image, tile order / tickets and epilogues as v6, but FOUR waves,
 // one per SIMD, each a 128 x 128 sub-tile = 8 x 8 fragments of v_mfma_f32_16x16x32_bf16 whose 256 fp32 accumulators are the
@@ -979,25 +967,7 @@ struct G8 {
   }
 };
 
-// gap placement of one k-tile (dev sweep: -DGEMM8_...)
-#ifndef GEMM8_BAR1
-#define GEMM8_BAR1 36        // phase 1: lgkmcnt(0) + barrier (behind the 16 second-half reads: gaps 0, RD, .. 15 RD)
-#endif
-#ifndef GEMM8_DMAS
-#define GEMM8_DMAS 3         // gaps between DMA pieces (never back to back: the four waves run in step and the CU has one address path)
-#endif
-#ifndef GEMM8_BAR2
-#define GEMM8_BAR2 30        // phase 2: vmcnt + barrier, then the next tile's first-half reads in gaps BAR2 + RD, + 2 RD, ..
-#endif
-#ifndef GEMM8_RD
-#define GEMM8_RD 2           // gaps between fragment reads (16 per phase): phase 1 in gaps 0, RD, 2 RD ..; phase 2 in gaps BAR2 + RD, BAR2 + 2 RD ..
-#endif
-#ifndef GEMM8_FINEWAIT
-#define GEMM8_FINEWAIT 1     // 1: the loop-top wait for the first-half fragments is split per activation fragment (counted lgkmcnt) instead of
-#endif                       //    one lgkmcnt(0): only the 8 weight fragments + the first activation fragment gate the first MFMA
-#ifndef GEMM8_PF
-#define GEMM8_PF 0           // 1: two L2 prefetch ops per wave and k-tile behind the DMA pieces (G8::prefetch).  Measured on v8
-#endif                       // (profiles/r04d_gemm_v8_sweep.log): ffn2 +4 % (= v6's level), but qkv -1 %, ffn0 -4 %: off, ffn2 stays on v6
+// gap placement of one k-tile: GEMM8_BAR1 / _DMAS / _BAR2 / _RD / _FINEWAIT / _PF (dev_knobs.h)
 // S: ring stage of this tile; ISSUE: tile t+2 exists (fetch it into stage S); NEXT: tile t+1 exists (read its first half)
 template <int S, bool ISSUE, bool NEXT, bool FIRST = false> MMPL_DEV void gemm8_tile(G8& k) {
   constexpr int D1 = GEMM8_BAR1 + 2;                                   // first DMA gap of phase 1
@@ -1059,8 +1029,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int frow = lane & 15, fchunk = lane >> 4;
-  [[maybe_unused]] unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;      // dev: -DGEMM6_TIMING=1 (as gemm_bf16_v6_kernel)
-  if constexpr (GEMM6_TIMING) tk0 = __builtin_readcyclecounter();
+  GEMM_DEV_TICKS;
+  GEMM_DEV_TICK(tk0);
   asm volatile("s_nop 0" ::: MMPL_ALL_AGPRS);
 
   G8 k;
@@ -1139,7 +1109,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     sfor<16>([&k](auto r) { k.template lds<0, 0, decltype(r)::value>(); });
 
-    if constexpr (GEMM6_TIMING) tk1 = __builtin_readcyclecounter();
+    GEMM_DEV_TICK(tk1);
     int t = 0;
     if (nt >= 4) {
       gemm8_tile<0, true, true, true>(k);
@@ -1164,7 +1134,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // every wave is past the last tile's phase-1 barrier: nobody reads the ring any more, the epilogue stages through it.
     // (the MFMA results need their passes before a VALU instruction may read the accumulator file)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-    if constexpr (GEMM6_TIMING) tk2 = __builtin_readcyclecounter();
+    GEMM_DEV_TICK(tk2);
 
     // ---- epilogue: v6's, on the two 128 x 64 halves of the wave's sub-tile.  Its lane-dependent addresses are derived from an
     // OPAQUE copy of the lane id defined here: otherwise hipcc hoists them above the k loop and, short of VGPRs there, parks them
@@ -1218,6 +1188,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         gemm_epilogue<EPI>(g, acc[1], mw + 64, nw0 + 64 * nh, frow_e, fchunk_e);
       });
     }
+#ifdef MMPL_DEV_ABLATIONS
     if constexpr (GEMM6_TIMING) {      // per-wave { prologue, k loop, epilogue } shader cycles over the output (tools/bench_kernels.py gemmphases)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       tk3 = __builtin_readcyclecounter();
@@ -1230,6 +1201,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         tp[3] = (float)(2 * nt);
       }
     }
+#endif
     if (!persistent) return;
     __syncthreads();                 // the ring (and s_ticket) are free again
   }

@@ -22,6 +22,8 @@ WAN_CONFIGS: Dict[str, dict] = {
     # reduced configs for parity tests (head_dim stays 128 like both real models)
     "tiny": dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64, freq_dim=256),
     "small": dict(dim=512, ffn_dim=1280, num_heads=4, num_layers=3, text_dim=128, freq_dim=256),
+    # the depth at which the 408-forward trajectory tolerance is stated a second time (tests/golden/make_golden.py chunk50_deep)
+    "deep": dict(dim=512, ffn_dim=1536, num_heads=4, num_layers=8, text_dim=128, freq_dim=256),
 }
 
 

@@ -1,7 +1,7 @@
 """Generate golden fixtures by running the REAL reference (/root/reference, CPU, bf16) on seeded inputs.
 
 Build-container only (the reference never travels to the GPU box).  Usage:
-    python tests/golden/make_golden.py [dit] [chunk] [chunk50] [chunk50_gpu] [chunk_i2v] [chunk_i2v50] [sched] [vae]
+    python tests/golden/make_golden.py [dit] [chunk] [chunk50] [chunk50_gpu] [chunk50_deep:{cpu,gpu,perm,f32}] [chunk_i2v] [chunk_i2v50] [sched] [vae]
 Writes tests/golden/*.pt.  Inputs are regenerated from seeds by the tests (mmpl_amd.synthetic), so the
 fixtures hold expected OUTPUTS of the reference (full or strided + sha256), plus known-answer scalars.
 While generating, the oracle restatement (oracle/) is run on the same inputs and its agreement with the
@@ -353,6 +353,78 @@ def gen_chunk50_gpu_semantics(steps=50):
                     meta=dict(m)), os.path.join(HERE, "chunk_t2v_tiny_50_gpu_semantics.pt"))
 
 
+def gen_chunk50_deep(which, steps=50, cfg_name="deep"):
+    """The 408-forward T2V chunk of `gen_chunk50` / `gen_chunk50_gpu_semantics` on a DEEPER synthetic model (WAN_CONFIGS["deep"]:
+    8 layers, dim 512, 4 heads; the tiny model has 2 / 256 / 2): how a per-forward difference compounds over 50 UniPC steps x CFG 5
+    depends on the depth, and the per-forward HIP-vs-reference distance at 30 / 40 layers is ~5 x the tiny model's (DESIGN.md
+    section 4).  Every run is the REAL reference (its model, its unedited UniPC step); one run is about an hour of 8 cores, so the
+    runs are separate steps that each update chunk_t2v_deep_50.pt:
+        cpu   the reference as is (CPU scalar semantics)                       -> out_strided / handoff_strided / sha
+        gpu   scheduler.sigmas carrying `_GpuScalar` (the reference's native platform)  -> gpu_* entries: what the HIP pipeline is held to
+        perm  the `gpu` run with only the K/V gather order of its self-attention reversed -> noise_floor order_* (the bound's unit)
+        f32   the same weights in fp32 (CPU semantics; a scalar is fp32 either way)      -> noise_floor f32_*
+    The oracle's own distance is NOT measured here (an hour more); tests/test_trajectory_gpu.py compares the HIP pipeline with the
+    stored reference outputs directly."""
+    fps, model, attn, _, unipc, sched = load_reference()
+    path = os.path.join(HERE, "chunk_t2v_deep_50.pt")
+    meta = dict(cfg=cfg_name, weight_seed=3, ctx_seeds=(31, 32), n_valid=(40, 12), noise_seed=33, renoise_seed_base=200, steps=steps,
+                guidance=5.0, shift=5.0)
+    fx = torch.load(path) if os.path.exists(path) else dict(meta=meta, noise_floor={}, seconds={},
+                                                            produced_by="the REAL reference (CausalFPSWanModel + FlowUniPCMultistepScheduler.step, "
+                                                                        "unedited); make_golden.py gen_chunk50_deep")
+    assert fx["meta"] == meta, (fx["meta"], meta)
+    cfg, ctxs, noise, renoise = _chunk_inputs(meta)
+    mdl, sd, _ = build_ref_model(fps, cfg_name, seed=meta["weight_seed"])
+    t0 = time.time()
+    tick = lambda si: print(f"[chunk50_deep {which}] stage {si} done at {time.time() - t0:.0f}s", flush=True)
+    real_attention = fps.attention
+    if which == "cpu":
+        out, hand = _ref_stage_loop(mdl, fps, unipc, sched, cfg, noise.clone(), renoise, ctxs, steps, progress=tick)
+        fx.update(out_sha=sha(out), out_strided=out[..., ::2, ::2].clone(), handoff_sha=sha(hand), handoff_strided=hand[..., ::3, ::3].clone())
+    elif which == "gpu":
+        _check_gpu_scalar_shim(unipc)
+        out, hand = _ref_stage_loop(mdl, fps, unipc, sched, cfg, noise.clone(), renoise, ctxs, steps, progress=tick, gpu_scalars=True)
+        fx.update(gpu_out_sha=sha(out), gpu_out_strided=out[..., ::2, ::2].clone(), gpu_handoff_sha=sha(hand),
+                  gpu_handoff_strided=hand[..., ::3, ::3].clone())
+    elif which == "perm":
+        def permuted_attention(q, k, v, *a, **kw):
+            n = k.shape[1] // S480
+            idx = torch.arange(n * S480).view(n, S480).flip(0).reshape(-1)
+            return real_attention(q, k[:, idx], v[:, idx], *a, **kw)
+        fps.attention = permuted_attention
+        out, hand = _ref_stage_loop(mdl, fps, unipc, sched, cfg, noise.clone(), renoise, ctxs, steps, progress=tick, gpu_scalars=True)
+        fps.attention = real_attention
+        fx.update(gpu_perm_out_strided=out[..., ::2, ::2].clone(), gpu_perm_handoff_strided=hand[..., ::3, ::3].clone())
+    elif which == "f32":
+        m32 = fps.CausalFPSWanModel(model_type="t2v", dim=cfg["dim"], ffn_dim=cfg["ffn_dim"], num_heads=cfg["num_heads"],
+                                    num_layers=cfg["num_layers"], text_dim=cfg["text_dim"], freq_dim=cfg["freq_dim"]).eval()
+        m32.load_state_dict({k: v.float() for k, v in sd.items()}, strict=True)
+        f32_attention = lambda q, k, v, *a, **kw: real_attention(q, k, v, *a, **dict(kw, dtype=torch.float32))
+        fps.attention, model.flash_attention = f32_attention, f32_attention
+        out, hand = _ref_stage_loop(m32, fps, unipc, sched, cfg, noise.clone(), renoise, [c.float() for c in ctxs], steps, dtype=torch.float32,
+                                    progress=tick)
+        fps.attention, model.flash_attention = real_attention, attn.attention
+        fx.update(out_f32_strided=out[..., ::2, ::2].to(torch.bfloat16).clone(), handoff_f32_strided=hand[..., ::3, ::3].to(torch.bfloat16).clone())
+    else:
+        raise SystemExit(f"chunk50_deep: unknown run {which!r}")
+    fx["seconds"][which] = time.time() - t0
+    nf = fx["noise_floor"]
+    have = lambda *ks: all(k in fx for k in ks)
+    if have("gpu_out_strided", "out_strided"):
+        nf.update(gpu_vs_cpu_semantics_out=rel_l2(fx["gpu_out_strided"], fx["out_strided"]),
+                  gpu_vs_cpu_semantics_handoff=rel_l2(fx["gpu_handoff_strided"], fx["handoff_strided"]))
+    if have("gpu_out_strided", "gpu_perm_out_strided"):
+        nf.update(order_out=rel_l2(fx["gpu_perm_out_strided"], fx["gpu_out_strided"]),
+                  order_handoff=rel_l2(fx["gpu_perm_handoff_strided"], fx["gpu_handoff_strided"]))
+    if have("out_f32_strided", "out_strided"):
+        nf.update(f32_out=rel_l2(fx["out_strided"], fx["out_f32_strided"]), f32_handoff=rel_l2(fx["handoff_strided"], fx["handoff_f32_strided"]))
+    if have("out_f32_strided", "gpu_out_strided"):
+        nf.update(gpu_vs_f32_out=rel_l2(fx["gpu_out_strided"], fx["out_f32_strided"]))
+    print(f"[chunk50_deep {which}] {fx['seconds'][which]:.0f}s  rms={out.float().pow(2).mean().sqrt().item():.3f}  noise floors so far: "
+          + ", ".join(f"{k}={v:.3e}" for k, v in nf.items()), flush=True)
+    torch.save(fx, path)
+
+
 def _check_gpu_scalar_shim(unipc):
     """The shim on the toy trajectory: reference + `_GpuScalar` == FlowUniPCRef(gpu_scalar_semantics=True), bit for bit, and it differs
     from the plain CPU run (else the shim did nothing)."""
@@ -463,6 +535,9 @@ if __name__ == "__main__":
         gen_chunk50()
     if "chunk50_gpu" in what:
         gen_chunk50_gpu_semantics()
+    for w in what:                                   # chunk50_deep:cpu | :gpu | :perm | :f32  (about an hour of 8 cores each)
+        if w.startswith("chunk50_deep:"):
+            gen_chunk50_deep(w.split(":", 1)[1])
     if "chunk_i2v" in what:
         gen_chunk_i2v()
     if "chunk_i2v50" in what:
