@@ -110,6 +110,11 @@ def parse():
                     help="NOT the headline: the statistics real checkpoints have and unit-variance synthetic weights do not (QK-norm gains x8, "
                          "six massive-activation channels -- the weights of tests/test_fullsize_gpu.py's heavy-tail case): how much of the "
                          "self-attention kernel's speed is its max-free FAST pass?  Reports attn_blocks_redone_fraction next to the attention ms")
+    ap.add_argument("--heavy-tail-heads", type=float, default=None, metavar="P",
+                    help="with --heavy-tail: the QK-norm gain only on a fraction P of every layer's heads (their 128 norm channels; a seeded draw "
+                         "per layer) -- closer to a real checkpoint than every head x gain; the massive-activation channels stay")
+    ap.add_argument("--no-attn-history", action="store_true",
+                    help="A/B: stateless self-attention (no per-block pass history; every block whose FAST pass fails pays for both passes every step)")
     ap.add_argument("--cpu-budget-s", type=float, default=150.0, help="stop adding stage shapes to the CPU baseline after this many seconds")
     return ap.parse_args()
 
@@ -326,10 +331,17 @@ def run_wavefront(args, dist, rank, world, dev, gloo):
     lat_ho = {c: st["t_recv_done"] - max(st.get("t_sink", 0.0), st.get("t_ready", 0.0)) for c, st in ho_stats.items() if "t_recv_done" in st}
     wait_ho = {c: max(0.0, st["t_sink"] - st["t_ready"]) for c, st in ho_stats.items() if "t_sink" in st and "t_ready" in st}
     full = args.sampling_steps == 50
-    # every stage of every chunk runs 2 K + 2 forwards (K denoise steps x (cond, uncond) + the refresh pair), the hand-off and the
-    # consumer's VAE transform do not shrink with K: wall x 102 / (2 K + 2) is what the same wavefront takes at the reference's 50 steps
-    # up to those fixed costs (which the shortened run over-weights: the scaled value is a slight UNDER-estimate)
-    to_50 = 102.0 / (2.0 * args.sampling_steps + 2.0)
+    # Forwards per stage at K UniPC steps (casual_fps_inference.py:266-439): 2 K + 2 (K denoise steps x (cond, uncond) + the refresh pair),
+    # except the stage that does not persist its K / V ([13..18]: 2 K, no refresh pair -- the pipeline skips it, :283) and the first stage
+    # of chunks >= 2 (2: the refresh pair on the handed-over frames, whatever K is).  The wall clock of the shortened run is scaled by
+    # the FLOP-weighted ratio of those counts at 50 and at K over all chunks of the video -- per stage, not one 102 / (2 K + 2) for
+    # everything (which over-states `value` for K < 50: ~0.6 % at K = 27, ~10 % at K = 2).  What does not shrink with K (hand-off, the
+    # consumer's VAE transform) is over-weighted by the shortened run, which pulls the scaled value DOWN; the FLOP weights stand in for
+    # measured stage times, whose error has no known sign: `value_shortened_run` is the measurement, `value` its projection.
+    def chunk_fwd_flops(K, first):
+        n = [2 * K + 2 if first else 2, 2 * K + 2, 2 * K + 2, 2 * K]
+        return sum(f * k for f, k in zip(stage_flops, n))
+    to_50 = (sum(chunk_fwd_flops(50, c == 0) for c in range(C_)) / sum(chunk_fwd_flops(args.sampling_steps, c == 0) for c in range(C_)))
     value_raw = 21.0 * C_ / wall
     value = value_raw / to_50
     # the occupancy model of the default N > 1 line, fed by THIS run's chunk / anchor times (kept for comparison)
@@ -337,8 +349,7 @@ def run_wavefront(args, dist, rank, world, dev, gloo):
     later_anchor = anchor[1:] if len(anchor) > 1 else anchor
     d_mean, a_mean = sum(later) / len(later), sum(later_anchor) / len(later_anchor)
     modelled = min(float(n_lanes), d_mean / a_mean) * 21.0 / (d_mean * to_50)
-    fwd_per_chunk = [(args.sampling_steps * 2 + 2) for _ in range(4)]
-    flops = sum(f * n for f, n in zip(stage_flops, fwd_per_chunk)) * C_          # (chunks >= 2 skip s0's denoising: upper bound)
+    flops = sum(chunk_fwd_flops(args.sampling_steps, c == 0) for c in range(C_))
     n_fwd_steps = sum(1 for c in order for _ in range(4 if c == 0 else 3)) * (args.sampling_steps + 1)
     res = {"metric": "video_latent_frames_per_sec", "value": value, "unit": "latent-frames/s",
            "n_gpus": dist.get_world_size() if dist is not None else 1, "steps": args.steps, "warmup": args.warmup,
@@ -349,10 +360,11 @@ def run_wavefront(args, dist, rank, world, dev, gloo):
                                   "not a scaling measurement"} if gloo else {}),
            **({} if full else {"value_shortened_run": value_raw,
                                "value_scaling": f"the run used {args.sampling_steps} UniPC steps per stage instead of the reference's 50 (wall-clock budget "
-                                                f"{args.wavefront_budget_s:.0f} s); `value` = 21 C / (wall x {to_50:.3f}), wall x 102 / (2 K + 2): every stage's "
-                                                "time is proportional to its 2 K + 2 forwards, the hand-off / VAE consumer transform is not (so `value` is a "
-                                                "slight under-estimate); `value_shortened_run` = 21 C / wall of the run as it was; --sampling-steps 50 measures "
-                                                "the full length"}),
+                                                f"{args.wavefront_budget_s:.0f} s); `value` = 21 C / (wall x {to_50:.3f}): the FLOP-weighted ratio of the forwards "
+                                                "every stage of every chunk runs at 50 steps and at K (2 K + 2 per stage; 2 K for the stage that does not persist "
+                                                "its K / V; 2 for the first stage of chunks >= 2).  The hand-off / VAE consumer transform do not shrink with K "
+                                                "(pulls `value` down); FLOP weights stand in for stage times (sign unknown): `value_shortened_run` = 21 C / wall "
+                                                "is the measurement, `value` its projection to the reference's length; --sampling-steps 50 measures it"}),
            "config": {"workload": f"Wan2.1-T2V-{args.model} {args.res}: ONE video of {C_} chunks (21 latent frames each) through the real pipeline, "
                                   f"{args.sampling_steps} UniPC steps x CFG per stage, anchors handed lane -> lane + 1",
                       "frame_seqlen": S, "latent_hw": [lat_h, lat_w], "sampling_steps": args.sampling_steps, "guidance_scale": 5.0,
@@ -443,9 +455,17 @@ def main():
         eng = DitEngine(cfg, lat_h, lat_w, dev)
         sd = dit_state_dict(cfg, seed=1234, device=dev)
         if args.heavy_tail:
+            H = cfg["num_heads"]
             for l in range(cfg["num_layers"]):
+                mult = torch.full([H], args.heavy_tail_gain)
+                if args.heavy_tail_heads is not None:                 # only round(P * H) heads of this layer (seeded per layer)
+                    gsel = torch.Generator().manual_seed(4321 + l)
+                    heavy = torch.randperm(H, generator=gsel)[:max(0, min(H, round(args.heavy_tail_heads * H)))]
+                    mult = torch.ones(H)
+                    mult[heavy] = args.heavy_tail_gain
+                mult = mult.repeat_interleave(128).to(dev)
                 for k in ("self_attn.norm_q.weight", "self_attn.norm_k.weight"):
-                    sd[f"blocks.{l}.{k}"] = (sd[f"blocks.{l}.{k}"].float() * args.heavy_tail_gain).to(torch.bfloat16)
+                    sd[f"blocks.{l}.{k}"] = (sd[f"blocks.{l}.{k}"].float() * mult).to(torch.bfloat16)
             b = sd["patch_embedding.bias"].float()
             cols = [c % cfg["dim"] for c in (7, 300, 1111, 2049, 3333, 5000)]
             b[cols] = torch.tensor([60.0, -60.0, 45.0, -45.0, 60.0, -50.0], device=b.device)
@@ -490,7 +510,10 @@ def main():
         x36 = None
         if args.i2v_model:                                  # x = [latents | conditioning video y (mask + image latents, 20 channels)]
             x36 = torch.randn(len(frames), 36, lat_h, lat_w, device=dev).to(torch.bfloat16)
-        stage_state.append(dict(frames=frames, lat=lat, x36=x36, sched=sched, vis=vis, ws=plan.write_slots(frames),
+        # the self-attention's pass history: one per (stage, CFG branch), like the pipeline's (it keeps one per branch and zeroes it per
+        # stage; the rotation here interleaves the stages, so each keeps its own)
+        hist = [None, None] if args.no_attn_history else [eng.new_attn_history(len(frames)) for _ in range(2 if pair is None else 1)]
+        stage_state.append(dict(frames=frames, lat=lat, x36=x36, sched=sched, vis=vis, ws=plan.write_slots(frames), hist=hist,
                                 fc=flow[0], fu=flow[1], flow=flow, mine=torch.empty_like(lat),
                                 t=torch.empty(len(frames), dtype=torch.float32, device=dev)))
     handoff_send = torch.zeros(8, 16, lat_h, lat_w, device=dev, dtype=torch.bfloat16)
@@ -524,14 +547,14 @@ def main():
         if pair is None:
             for which, out in ((0, st["fc"]), (1, st["fu"])):
                 kc, vc, ck, cv, crows = caches[which]
-                eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out, cross_rows=crows)
+                eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out, cross_rows=crows, attn_history=st["hist"][which])
         else:
             kc, vc, ck, cv, crows = caches[0]
             if st.get("fwd_graph") is not None and not eager:
                 xin(st)                                # (refreshes the 36-channel buffer of the i2v model type)
                 st["fwd_graph"].replay()               # this rank's branch: one hipGraph per forward
             else:
-                eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=st["mine"], cross_rows=crows)
+                eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=st["mine"], cross_rows=crows, attn_history=st["hist"][0])
             pair.exchange(st["mine"], st["flow"])      # host-issued 2-rank all-gather: the step cannot be ONE graph here
         sched.step_cfg(st["fc"], st["fu"], 5.0, st["lat"])
         if i % 4 == 1:
@@ -582,7 +605,7 @@ def main():
             for which, out in ((0, st["fc"]), (1, st["fu"])):
                 kc, vc, ck, cv, crows = caches[which]
                 st["t"].fill_(999.0)
-                eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out, cross_rows=crows)
+                eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out, cross_rows=crows, attn_history=st["hist"][which])
             sched = st["sched"]
             sched.build_step_table(5.0, dev)
             sched._ensure_state(st["lat"])
@@ -602,25 +625,29 @@ def main():
                     main = torch.cuda.current_stream()
                     st["side"].wait_stream(main)                      # fork: the uncond branch on a second captured stream
                     kc, vc, ck, cv, crows = caches[0]
-                    eng.forward(x_in, st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=st["fc"], cross_rows=crows)
+                    eng.forward(x_in, st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=st["fc"], cross_rows=crows, attn_history=st["hist"][0])
                     with torch.cuda.stream(st["side"]):
                         kc, vc, ck, cv, crows = caches[1]
-                        eng.forward(x_in, st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=st["fu"], cross_rows=crows, workspace=st["ws2"])
+                        eng.forward(x_in, st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=st["fu"], cross_rows=crows, workspace=st["ws2"],
+                                    attn_history=st["hist"][1])
                     main.wait_stream(st["side"])                      # join
                 else:
                     for which, out in ((0, st["fc"]), (1, st["fu"])):
                         kc, vc, ck, cv, crows = caches[which]
                         eng.forward(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, out=out, cross_rows=crows,
-                                    share_out=st["share"] if which == 0 else None, share_in=st["share"] if which == 1 else None)
+                                    share_out=st["share"] if which == 0 else None, share_in=st["share"] if which == 1 else None,
+                                    attn_history=st["hist"][which])
                 sched.step_cfg_table(st["fc"], st["fu"], st["lat"], st["t"])
             st["graph"], st["replays"] = g, 0
     concurrent_stages = [i for i, st in enumerate(stage_state) if st.get("concurrent")]
+    stage_state_share = [st.get("share") is not None for st in stage_state]      # (stage_state is cleared before the VAE leg)
     if pair is not None and not args.eager:
         # CFG pair: each rank's forward is a hipGraph (the per-step exchange of the two flow predictions is issued by the host)
         for st in stage_state:
             kc, vc, ck, cv, crows = caches[0]
             st["t"].fill_(999.0)
-            st["fwd_graph"] = eng.capture(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, st["mine"], cross_rows=crows)
+            st["fwd_graph"] = eng.capture(xin(st), st["t"], st["frames"], st["ws"], st["vis"], kc, vc, ck, cv, st["mine"], cross_rows=crows,
+                                          attn_history=st["hist"][0])
     # same-run calibration of THIS box: what it sustains on nothing but MFMAs (random operands), per instruction shape, right before
     # the warm-up steps (which bring clocks / power back to the workload's own steady state before the timed region)
     probe = None
@@ -655,7 +682,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     step_s = [e0.elapsed_time(e1) * 1e-3 for e0, e1 in ev]
-    attn_blocks, attn_redone, attn_waves_bad = eng.read_attn_stats() if attn_stats is not None else (None, None, None)   # of the timed region (graph replays included)
+    attn_blocks, attn_redone, attn_waves_bad, attn_predicted = eng.read_attn_stats() if attn_stats is not None else (None, None, None, None)   # of the timed region (graph replays included)
     # ---- eager pass (after the timed region when that one replayed graphs): one rotation of the four stages with a hipEvent
     # pair around every self-attention launch (all kernel classes with --profile-all) -> `eager` figures and `roofline`
     eager_step_s = None
@@ -721,6 +748,18 @@ def main():
         value = lanes_busy * 21.0 / chunk_s
         chunk_flops = 102.0 * sum(stage_flops)
         achieved_pf = (2.0 if pair is None else 1.0) * 51.0 * sum(stage_flops) / chunk_s / 1e15    # forwards per rank-step
+        # ... and the FLOPs of the launches that are actually in the timed steps: the text cross-attention over the collapsed key set,
+        # and block 0's self-attention + output projection once per step where the branches run back to back (share_out / share_in)
+        from mmpl_amd.stage_plan import dit_forward_flops_executed
+        exec_step = []
+        for si, (q, kv) in enumerate(stage_shapes):
+            st_share = use_graph and stage_state_share[si]
+            T_txt = cfg.get("text_len", 512)
+            keys = lambda rows: rows + 1 if 0 <= rows <= T_txt - 2 else T_txt          # mmpl_dit_forward's cross_rows rule
+            per_branch = [dit_forward_flops_executed(cfg, S, q, kv, keys(caches[b][4]), block0_self_attn_shared=(b == 1 and st_share))
+                          for b in range(len(caches))]
+            exec_step.append(sum(per_branch))
+        executed_pf = 51.0 * sum(exec_step) / chunk_s / 1e15
         res = {
             "metric": "video_latent_frames_per_sec", "value": value, "unit": "latent-frames/s",
             "n_gpus": dist.get_world_size() if dist is not None else 1,        # the ranks RCCL actually connected
@@ -751,14 +790,27 @@ def main():
             "sec_per_chunk_extrapolated": chunk_s,
             "achieved_pflops_per_gpu": achieved_pf,
             "mfma_frac_whole_step": achieved_pf * 1e3 / MFMA_PEAK_TFLOPS,
+            "executed_pflops_per_gpu": executed_pf,
+            "mfma_frac_executed": executed_pf * 1e3 / MFMA_PEAK_TFLOPS,
+            "flop_accounting": "achieved_* = the reference's algorithmic FLOPs (SURVEY.md 8d: both CFG branches in full, 512 cross-attention keys) / time; "
+                               "executed_* = the FLOPs of the launches in the timed step graphs (cross-attention over the collapsed key set; block 0's "
+                               "self-attention + o-projection once per step where share_out / share_in applies).  The chunk model prices the refresh "
+                               "pair of a stage as one more step (the pipeline replays the per-forward graphs there, without the share: < 0.02 % of a chunk)",
             "vae_decode_s_per_chunk": vae_s,
             # data dependence of the self-attention kernel IN THE TIMED REGION: 256-row query blocks whose max-free FAST softmax pass
             # overflowed / underflowed and were redone by the GENERAL pass (attn_w64.hip); caches hold K / V written by real forwards
             **({"attn_blocks": attn_blocks, "attn_blocks_redone": attn_redone,
                 "attn_blocks_redone_fraction": (attn_redone / attn_blocks) if attn_blocks else None,
                 # per WAVE (64 of a block's 256 query rows): how many held a failing row themselves -- what a finer redo unit would pay for
-                "attn_waves_failed_fraction": (attn_waves_bad / (4.0 * attn_blocks)) if attn_blocks else None} if attn_stats is not None else {}),
-            **({"weights": f"heavy-tailed synthetic (QK-norm gains x{args.heavy_tail_gain:g}, six massive-activation channels): NOT the headline workload"}
+                "attn_waves_failed_fraction": (attn_waves_bad / (4.0 * attn_blocks)) if attn_blocks else None,
+                # blocks their history byte (the previous step's failure) sent straight to the GENERAL pass: 1.66 FAST-pass times instead of 2.66
+                "attn_blocks_predicted": attn_predicted,
+                "attn_blocks_predicted_fraction": (attn_predicted / attn_blocks) if attn_blocks else None} if attn_stats is not None else {}),
+            "attn_history": "off (--no-attn-history): stateless self-attention" if args.no_attn_history else
+                            "on: one byte per (stage, branch, layer, head, 256-row query block) carried from step to step (include/mmpl_hip.h)",
+            **({"weights": f"heavy-tailed synthetic (QK-norm gains x{args.heavy_tail_gain:g}" +
+                           (f" on {args.heavy_tail_heads:g} of every layer's heads" if args.heavy_tail_heads is not None else "") +
+                           ", six massive-activation channels): NOT the headline workload"}
                if args.heavy_tail else {}),
         }
         if eager_step_s is not None:
@@ -772,7 +824,7 @@ def main():
             traffic, traffic_src = None, None
             if args.model == "14B" and args.res == "720p" and args.mode == "t2v" and not args.heavy_tail:
                 # Fabric bytes per op cannot be collected inside this process (rocprofv3 --pmc wraps the program): the committed PMC
-                # passes over THIS command (tools/r03_profiles.sh: bench.py under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+                # passes over THIS command (tools/r06_gpu.sh hbm: bench.py under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
                 # passes, mean over the rotation's self-attention ops).  The file is named explicitly by profiles/PMC_TRAFFIC.json,
                 # written by the collection script -- not picked by a sorted glob.
                 idx = os.path.join(ROOT, "profiles", "PMC_TRAFFIC.json")

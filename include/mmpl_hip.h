@@ -6,7 +6,8 @@
  *
  * Conventions: every pointer marked "dev" is a borrowed device pointer (e.g. torch.Tensor.data_ptr()); nothing
  * is retained after the call returns except by mmpl_dit_bind_weights (which stores the weight pointers) and
- * nothing is allocated on the device except two 256 KiB RoPE tables owned by the handle.  All tensors are
+ * nothing is allocated on the device except two 256 KiB RoPE tables owned by the handle (and, under MMPL_CHECK_SHARE=1, 64 bytes of
+ * check state).  All tensors are
  * bfloat16 unless stated.  Every call takes the HIP stream to enqueue on and is asynchronous with respect to
  * the host.  Return value: 0 = ok, non-zero = error (text via mmpl_last_error(), thread-local).
  */
@@ -64,10 +65,12 @@ int mmpl_dit_precompute_context(MmplDit* h, const void* context, void* cross_k, 
 int mmpl_dit_set_image_kv(MmplDit* h, const void* img_k, const void* img_v, int n_img_tokens);
 
 /* Optional diagnostics of the self-attention kernel's data dependence.  attn_w64_kernel runs a max-free FAST softmax pass per
- * 256-row query block and redoes the block with the GENERAL (running-reference) pass if any row sum left [2^-40, 2^100].
- * stats_dev: 3 x uint64 in device memory (borrowed; zero them yourself), incremented by every self-attention launch of
- * mmpl_dit_forward on this handle, inside hipGraph replays too: [0] += blocks run, [1] += blocks redone, [2] += waves (64 of a
- * block's 256 query rows) that held a failing row themselves -- the unit a finer-grained redo would pay for.  NULL switches it off. */
+ * 256-row query block and redoes the block with the GENERAL (running-reference) pass if any row sum left [2^-100, 2^100].
+ * stats_dev: 4 x uint64 in device memory (borrowed; zero them yourself), incremented by every self-attention launch of
+ * mmpl_dit_forward on this handle, inside hipGraph replays too: [0] += blocks run, [1] += blocks whose FAST pass failed and that were
+ * redone (both passes paid), [2] += waves (64 of a block's 256 query rows) that held a failing row themselves -- the unit a
+ * finer-grained redo would pay for, [3] += blocks their history byte sent straight to the GENERAL pass (`attn_history`).  NULL
+ * switches it off. */
 int mmpl_dit_set_attn_stats(MmplDit* h, void* stats_dev);
 
 /* CausalFPSWanModel._forward_inference (causal_fps_model.py:708-837) behind WanFPSWrapper.forward
@@ -92,11 +95,28 @@ int mmpl_dit_set_attn_stats(MmplDit* h, void* stats_dev);
  *                caller's statement that ANOTHER forward on the same x_in / t / frame_ids / write_slots / visible_slots, whose
  *                layer-0 cache contents equal this one's, produced it: block 0's attention and output projection are skipped and
  *                x continues from share_in (this forward's own layer-0 K / V slots are still written).  Same kernels on the same
- *                inputs: the result is bit-identical to computing it. */
+ *                inputs: the result is bit-identical to computing it.  MMPL_CHECK_SHARE=1 (environment, read when the library is
+ *                first used; a debug switch) turns the statement into a check: the share_out and the share_in forward each
+ *                fingerprint the layer-0 K / V slots they attend to on the device (one pass over them), the share_in forward
+ *                compares; outside a stream capture it then fails with an error on a mismatch, inside one the mismatch is counted
+ *                on the device (mmpl_dit_share_check_failures).
+ *   attn_history (may be NULL): dev, mmpl_dit_attn_history_bytes(h, n_frames) bytes owned by the caller, one byte per (layer, head,
+ *                256-row query block, split part) of the self-attention: the OUTCOME of this attention's previous launch.  Hand the
+ *                same buffer to every forward of one (CFG branch, stage) -- consecutive denoise steps see the same K / V and nearly
+ *                the same q -- and zero it when the stage changes.  A query block whose max-free FAST softmax pass failed on the
+ *                previous launch (heavy-tailed scores) then starts in the GENERAL pass instead of paying for both (FAST is retried
+ *                after 8, then 16, then 31 launches so that the byte can clear).  Both passes are the exact softmax up to rounding,
+ *                so any contents give a correct result -- but WHICH pass runs decides the rounding: with a history the output bits
+ *                depend on the launches before (two identical sequences of launches from a zeroed history are bit-identical, eager or
+ *                replayed from a hipGraph); NULL = stateless, every launch bit-reproducible by itself. */
 int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int n_frames, const int* frame_ids,
                      const int* write_slots, const int* visible_slots, int n_visible, void* k_cache, void* v_cache,
                      int n_slots, const void* cross_k, const void* cross_v, int cross_rows, void* share_out, const void* share_in,
-                     void* out, void* workspace, size_t workspace_bytes, mmpl_stream_t stream);
+                     void* attn_history, void* out, void* workspace, size_t workspace_bytes, mmpl_stream_t stream);
+size_t mmpl_dit_attn_history_bytes(const MmplDit* h, int n_frames);
+/* MMPL_CHECK_SHARE=1: number of share_in forwards (eager or replayed) since the last call whose layer-0 K / V fingerprint differed
+ * from their share_out forward's; synchronises `stream` and resets the count.  0 when the switch is off. */
+int mmpl_dit_share_check_failures(MmplDit* h, long long* count, mmpl_stream_t stream);
 
 /* attention() seam (wan/modules/attention.py:139-185) over paged K/V.  q/o: row r, head h at base + r*ld + h*128; every base
  * 16-byte aligned, every leading dimension a multiple of 8 elements (rows are read and written 16 bytes per lane).
@@ -124,6 +144,15 @@ int mmpl_attn_fwd_ws(const void* q, int ldq, void* o, int ldo, const void* const
 int mmpl_attn_fwd_variant(const void* q, int ldq, void* o, int ldo, const void* const* k_pages, const void* const* v_pages,
                           int ldk, int ldv, int n_pages, int page_rows, int Lq, int num_heads, float softmax_scale,
                           void* workspace, size_t workspace_bytes, int variant, int cross, mmpl_stream_t stream);
+
+/* The DiT forward's self-attention launch by itself (variant 4 above: attn_w64_kernel on a q its producer multiplied by
+ * softmax_scale * log2(e) before rounding it to bf16), with the two optional pieces of state mmpl_dit_forward threads through it:
+ * history = mmpl_attn_history_bytes(Lq, num_heads) device bytes (see mmpl_dit_forward's attn_history; NULL = stateless) and
+ * stats_dev = 4 x uint64 (see mmpl_dit_set_attn_stats; NULL = off). */
+size_t mmpl_attn_history_bytes(int Lq, int num_heads);
+int mmpl_attn_fwd_history(const void* q, int ldq, void* o, int ldo, const void* const* k_pages, const void* const* v_pages,
+                          int ldk, int ldv, int n_pages, int page_rows, int Lq, int num_heads, float softmax_scale,
+                          void* workspace, size_t workspace_bytes, void* history, void* stats_dev, mmpl_stream_t stream);
 
 /* nn.Linear (+ fused epilogue). epi: 0 bias, 1 bias+GELU(tanh), 2 bias+SiLU, 3 x + (y*gate[frame]) , 4 x + y */
 int mmpl_gemm(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N, int K,

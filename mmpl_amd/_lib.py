@@ -10,8 +10,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmmpl_hip.so")
 # every symbol include/mmpl_hip.h declares (tests/test_abi.py checks this list against the header and the .so)
 SYMBOLS = [
     "mmpl_dit_num_weights", "mmpl_dit_weight_name", "mmpl_dit_create", "mmpl_dit_destroy", "mmpl_dit_bind_weights",
-    "mmpl_dit_workspace_bytes", "mmpl_dit_context_workspace_bytes", "mmpl_dit_precompute_context", "mmpl_dit_forward", "mmpl_dit_set_attn_stats", "mmpl_dit_set_image_kv", "mmpl_clip_visual", "mmpl_clip_visual_workspace_bytes",
-    "mmpl_attn_fwd", "mmpl_attn_fwd_ws", "mmpl_attn_fwd_variant", "mmpl_attn_workspace_bytes", "mmpl_gemm", "mmpl_gemm_tickets", "mmpl_gemm_scratch", "mmpl_gemm_scratch_bytes", "mmpl_device_xcd_round_robin", "mmpl_probe_mfma_tflops", "mmpl_layernorm", "mmpl_qknorm_rope", "mmpl_cfg_unipc_step", "mmpl_cfg_unipc_step_table",
+    "mmpl_dit_workspace_bytes", "mmpl_dit_context_workspace_bytes", "mmpl_dit_precompute_context", "mmpl_dit_forward", "mmpl_dit_attn_history_bytes", "mmpl_dit_share_check_failures", "mmpl_dit_set_attn_stats", "mmpl_dit_set_image_kv", "mmpl_clip_visual", "mmpl_clip_visual_workspace_bytes",
+    "mmpl_attn_fwd", "mmpl_attn_fwd_ws", "mmpl_attn_fwd_variant", "mmpl_attn_fwd_history", "mmpl_attn_history_bytes", "mmpl_attn_workspace_bytes", "mmpl_gemm", "mmpl_gemm_tickets", "mmpl_gemm_scratch", "mmpl_gemm_scratch_bytes", "mmpl_device_xcd_round_robin", "mmpl_probe_mfma_tflops", "mmpl_layernorm", "mmpl_qknorm_rope", "mmpl_cfg_unipc_step", "mmpl_cfg_unipc_step_table",
     "mmpl_vae_num_weights", "mmpl_vae_weight_name", "mmpl_vae_create", "mmpl_vae_destroy", "mmpl_vae_bind_weights",
     "mmpl_vae_workspace_bytes", "mmpl_vae_decode", "mmpl_vae_encode",
     "mmpl_t5_num_weights", "mmpl_t5_create", "mmpl_t5_destroy", "mmpl_t5_bind_weights", "mmpl_t5_workspace_bytes", "mmpl_t5_encode",
@@ -71,7 +71,13 @@ def load() -> C.CDLL:
     lib.mmpl_dit_context_workspace_bytes.restype = sz
     lib.mmpl_dit_precompute_context.argtypes = [vp, vp, vp, vp, vp, sz, C.POINTER(ci), vp]
     lib.mmpl_dit_forward.argtypes = [vp, vp, vp, ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), ci, vp, vp, ci, vp, vp,
-                                     ci, vp, vp, vp, vp, sz, vp]
+                                     ci, vp, vp, vp, vp, vp, sz, vp]
+    lib.mmpl_dit_attn_history_bytes.argtypes = [vp, ci]
+    lib.mmpl_dit_attn_history_bytes.restype = sz
+    lib.mmpl_dit_share_check_failures.argtypes = [vp, C.POINTER(C.c_longlong), vp]
+    lib.mmpl_attn_history_bytes.argtypes = [ci, ci]
+    lib.mmpl_attn_history_bytes.restype = sz
+    lib.mmpl_attn_fwd_history.argtypes = [vp, ci, vp, ci, C.POINTER(vp), C.POINTER(vp), ci, ci, ci, ci, ci, ci, cf, vp, sz, vp, vp, vp]
     lib.mmpl_attn_fwd.argtypes = [vp, ci, vp, ci, C.POINTER(vp), C.POINTER(vp), ci, ci, ci, ci, ci, ci, cf, vp]
     lib.mmpl_attn_fwd_ws.argtypes = [vp, ci, vp, ci, C.POINTER(vp), C.POINTER(vp), ci, ci, ci, ci, ci, ci, cf, vp, sz, vp]
     lib.mmpl_attn_fwd_variant.argtypes = [vp, ci, vp, ci, C.POINTER(vp), C.POINTER(vp), ci, ci, ci, ci, ci, ci, cf, vp, sz, ci, ci, vp]

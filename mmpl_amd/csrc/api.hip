@@ -102,7 +102,8 @@ struct MmplDit {
   float* cos_tab = nullptr;  // [1024][64]
   float* sin_tab = nullptr;
   std::vector<const bf16_t*> w;
-  unsigned long long* attn_stats = nullptr;    // mmpl_dit_set_attn_stats: {blocks, blocks redone} of the self-attention launches
+  unsigned long long* attn_stats = nullptr;    // mmpl_dit_set_attn_stats: 4 counters of the self-attention launches (header)
+  unsigned long long* share_chk = nullptr;     // MMPL_CHECK_SHARE=1: {producer fingerprint[2], consumer fingerprint[2], mismatches} (device)
   const bf16_t* G(int i) const { return w[i]; }
   const bf16_t* Lw(int l, int i) const { return w[NG + l * NL + i]; }
 };
@@ -171,6 +172,12 @@ int mmpl_dit_create(const MmplDitConfig* cfg, MmplDit** out) {
   }
   hipMemcpy(h->cos_tab, c.data(), c.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(h->sin_tab, s.data(), s.size() * 4, hipMemcpyHostToDevice);
+  if (mmpl_config().check_share) {
+    if (hipMalloc(&h->share_chk, 8 * sizeof(unsigned long long)) != hipSuccess || hipMemset(h->share_chk, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
+      mmpl_dit_destroy(h);
+      return fail("mmpl_dit_create", "hipMalloc of the share-check state failed");
+    }
+  }
   *out = h;
   return 0;
 }
@@ -179,6 +186,7 @@ void mmpl_dit_destroy(MmplDit* h) {
   if (!h) return;
   if (h->cos_tab) hipFree(h->cos_tab);
   if (h->sin_tab) hipFree(h->sin_tab);
+  if (h->share_chk) hipFree(h->share_chk);
   delete h;
 }
 
@@ -332,7 +340,7 @@ int mmpl_dit_set_attn_stats(MmplDit* h, void* stats_dev) {
 int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, const int* frame_ids,
                      const int* write_slots, const int* visible_slots, int n_visible, void* k_cache, void* v_cache,
                      int n_slots, const void* cross_k, const void* cross_v, int cross_rows, void* share_out, const void* share_in,
-                     void* out, void* workspace, size_t workspace_bytes, mmpl_stream_t stream) {
+                     void* attn_history, void* out, void* workspace, size_t workspace_bytes, mmpl_stream_t stream) {
   if (!h || h->w.empty()) return fail("mmpl_dit_forward", "weights not bound");
   const MmplDitConfig& c = h->cfg;
   if (nF < 1 || nF > c.max_frames) return fail("mmpl_dit_forward", "n_frames out of range");
@@ -376,6 +384,25 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
   const size_t layer_stride = (size_t)n_slots * S * d;
   // rows cross_rows .. T-1 of the text K / V are one repeated row (the caller's statement, see the header); -1 = attend over all T
   const int ctx_n = (cross_rows >= 0 && cross_rows <= T - 2) ? cross_rows : -1;
+  const size_t hist_layer = mmpl_attn_history_bytes(Lq, H);
+  // MMPL_CHECK_SHARE=1: the producer (share_out) and the consumer (share_in) of block 0's shared self-attention fingerprint the layer-0
+  // K / V they attend to (after their own slot writes); the consumer compares.  The count of mismatches stays on the device
+  // (mmpl_dit_share_check_failures); an eager consumer forward reads it right away and fails.
+  const bool check_share = h->share_chk != nullptr && (share_out || share_in);
+  auto fingerprint_layer0 = [&](int which) -> int {
+    PageList pk{}, pv{};
+    for (int i = 0; i < n_visible; ++i) {
+      pk.p[i] = (const bf16_t*)k_cache + (size_t)visible_slots[i] * S * d;
+      pv.p[i] = (const bf16_t*)v_cache + (size_t)visible_slots[i] * S * d;
+    }
+    pk.n = pv.n = n_visible;
+    if (n_visible < 1) return 0;
+    HIP_TRY(mmpl_launch_share_check_zero(h->share_chk, which, s), "share check");
+    HIP_TRY(mmpl_launch_pages_fingerprint(pk, (size_t)S * d * sizeof(bf16_t), h->share_chk, which, s), "share check (K)");
+    HIP_TRY(mmpl_launch_pages_fingerprint(pv, (size_t)S * d * sizeof(bf16_t), h->share_chk, which, s), "share check (V)");
+    if (which == 1) HIP_TRY(mmpl_launch_share_check_compare(h->share_chk, s), "share check (compare)");
+    return 0;
+  };
   for (int l = 0; l < c.num_layers; ++l) {
     const bf16_t* em = w.emod + (size_t)l * nF * 6 * d;  // [nF][6][d]
     bf16_t* kc = (bf16_t*)k_cache + (size_t)l * layer_stride;
@@ -421,6 +448,7 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
         HIP_TRY(mmpl_launch_qknorm(a, s), "qk norm + rope + kv write");
       }
     }
+    if (l == 0 && check_share) TRY(fingerprint_layer0(share_in ? 1 : 0));
     if (take_shared) {
       HIP_TRY(hipMemcpyAsync(w.x, share_in, (size_t)Lq * d * sizeof(bf16_t), hipMemcpyDeviceToDevice, s), "shared block-0 x");
     } else {
@@ -444,6 +472,7 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
         a.split_ws = (float*)w.xn;                    // norm1's output is dead once the QKV GEMM has consumed it
         a.split_ws_bytes = (size_t)Lq * d * sizeof(bf16_t);
         a.redo_stats = h->attn_stats;
+        a.history = attn_history ? (unsigned char*)attn_history + (size_t)l * hist_layer : nullptr;
         ProfScope ps(K_ATTN_SELF, 4.0 * Lq * (double)np * S * d, s);
         HIP_TRY(mmpl_launch_attention(a, s), "self attention");
       }
@@ -502,6 +531,52 @@ int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int nF, c
   }
   TRY(gemm(w.xn, d, h->G(G_HEAD_W), d, h->G(G_HEAD_B), w.yh, 64, Lq, 64, d, EPI_BIAS, nullptr, 0, nullptr, 0, 1, s));
   HIP_TRY(mmpl_launch_unpatchify(w.yh, 64, (bf16_t*)out, nF, c.out_dim, c.lat_h, c.lat_w, s), "unpatchify");
+  if (check_share && share_in) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cs);
+    if (cs == hipStreamCaptureStatusNone) {                  // eager: fail this very call (inside a capture the count stays on the device)
+      long long n = 0;
+      TRY(mmpl_dit_share_check_failures(h, &n, stream));
+      if (n) return fail("mmpl_dit_forward", "MMPL_CHECK_SHARE: share_in was given but the layer-0 K / V this forward attends to differ from "
+                                             "the share_out forward's (the two CFG caches are out of step)");
+    }
+  }
+  return 0;
+}
+
+int mmpl_dit_share_check_failures(MmplDit* h, long long* count, mmpl_stream_t stream) {
+  if (!h || !count) return fail("mmpl_dit_share_check_failures", "null argument");
+  *count = 0;
+  if (!h->share_chk) return 0;                               // MMPL_CHECK_SHARE not set when the handle was created: nothing is checked
+  unsigned long long n = 0;
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemcpyAsync(&n, h->share_chk + 4, sizeof(n), hipMemcpyDeviceToHost, s), "share check read");
+  HIP_TRY(hipStreamSynchronize(s), "share check read");
+  if (n) HIP_TRY(hipMemsetAsync(h->share_chk + 4, 0, sizeof(n), s), "share check reset");
+  *count = (long long)n;
+  return 0;
+}
+
+size_t mmpl_dit_attn_history_bytes(const MmplDit* h, int n_frames) {
+  return h ? (size_t)h->cfg.num_layers * mmpl_attn_history_bytes(n_frames * h->S, h->cfg.num_heads) : 0;
+}
+size_t mmpl_attn_history_bytes(int Lq, int num_heads) { return (size_t)num_heads * ((Lq + 255) / 256) * 4; }
+
+int mmpl_attn_fwd_history(const void* q, int ldq, void* o, int ldo, const void* const* k_pages, const void* const* v_pages,
+                          int ldk, int ldv, int n_pages, int page_rows, int Lq, int num_heads, float softmax_scale,
+                          void* workspace, size_t workspace_bytes, void* history, void* stats_dev, mmpl_stream_t stream) {
+  if (n_pages < 1 || n_pages > MMPL_MAX_PAGES) return fail("mmpl_attn_fwd_history", "n_pages out of range");
+  if (reinterpret_cast<uintptr_t>(stats_dev) % 8) return fail("mmpl_attn_fwd_history", "stats must be 8-byte aligned");
+  AttnArgs a = {};
+  a.variant = ATTN_W64;
+  a.q_prescaled = 1;
+  a.q = (const bf16_t*)q; a.ldq = ldq; a.o = (bf16_t*)o; a.ldo = ldo; a.ldk = ldk; a.ldv = ldv; a.n_pages = n_pages;
+  a.page_rows = page_rows; a.Lq = Lq; a.H = num_heads; a.scale = softmax_scale;
+  a.split_ws = (float*)workspace; a.split_ws_bytes = workspace ? workspace_bytes : 0;
+  a.history = (unsigned char*)history;
+  a.redo_stats = (unsigned long long*)stats_dev;
+  for (int i = 0; i < n_pages; ++i) { a.k_pages[i] = (const bf16_t*)k_pages[i]; a.v_pages[i] = (const bf16_t*)v_pages[i]; }
+  HIP_TRY(mmpl_launch_attention(a, (hipStream_t)stream), "mmpl_attn_fwd_history");
   return 0;
 }
 

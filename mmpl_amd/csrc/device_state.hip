@@ -94,6 +94,7 @@ const MmplRuntimeConfig& mmpl_config() {
     c.gemm_v8 = num("MMPL_GEMM_V8", -1);
     c.vae_no_fuse_norm = flag("MMPL_VAE_NO_FUSE_NORM");
     c.ln_pipeline_min_rows = num("MMPL_LN_PIPELINE_MIN_ROWS", 16384);
+    c.check_share = flag("MMPL_CHECK_SHARE");
     return c;
   }();
   return cfg;

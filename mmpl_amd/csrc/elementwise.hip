@@ -531,6 +531,47 @@ hipError_t mmpl_launch_rows_equal_last(const bf16_t* x, int ld, int rows, int d,
   hipLaunchKernelGGL(rows_equal_last_kernel, dim3(rows), dim3(64), 0, s, x, ld, rows, d, flags);
   return hipGetLastError();
 }
+// ---- MMPL_CHECK_SHARE=1 (api.hip): position-sensitive 128-bit fingerprint of a list of equally sized pages: fp[0] += sum of the
+// 32-bit words, fp[1] += sum of word * (global word index + 1), both mod 2^64 (integer sums: independent of the order of the adds)
+__global__ __launch_bounds__(256) void pages_fingerprint_kernel(PageList pl, size_t words_per_page, unsigned long long* fp) {
+  const size_t total = (size_t)pl.n * words_per_page;
+  unsigned long long s1 = 0, s2 = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t pg = i / words_per_page, off = i - pg * words_per_page;
+    const unsigned long long w = reinterpret_cast<const uint32_t*>(pl.p[pg])[off];
+    s1 += w;
+    s2 += w * (unsigned long long)(i + 1);
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    s1 += __shfl_xor(s1, m, 64);
+    s2 += __shfl_xor(s2, m, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(fp, s1);
+    atomicAdd(fp + 1, s2);
+  }
+}
+// chk = {producer fp[2], consumer fp[2], mismatches}: which = 0 zeroes the producer's pair, 1 the consumer's
+__global__ void share_check_zero_kernel(unsigned long long* chk, int which) {
+  if (threadIdx.x < 2) chk[2 * which + threadIdx.x] = 0;
+}
+__global__ void share_check_compare_kernel(unsigned long long* chk) {
+  if (threadIdx.x == 0 && (chk[0] != chk[2] || chk[1] != chk[3])) chk[4] += 1;
+}
+hipError_t mmpl_launch_pages_fingerprint(const PageList& pl, size_t bytes_per_page, unsigned long long* chk, int which, hipStream_t s) {
+  if (pl.n < 1 || pl.n > MMPL_MAX_PAGES || bytes_per_page % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pages_fingerprint_kernel, dim3(2048), dim3(256), 0, s, pl, bytes_per_page / 4, chk + 2 * which);
+  return hipGetLastError();
+}
+hipError_t mmpl_launch_share_check_zero(unsigned long long* chk, int which, hipStream_t s) {
+  hipLaunchKernelGGL(share_check_zero_kernel, dim3(1), dim3(64), 0, s, chk, which);
+  return hipGetLastError();
+}
+hipError_t mmpl_launch_share_check_compare(unsigned long long* chk, hipStream_t s) {
+  hipLaunchKernelGGL(share_check_compare_kernel, dim3(1), dim3(64), 0, s, chk);
+  return hipGetLastError();
+}
 __global__ void zero_ints_kernel(int* p, int n) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
 }

@@ -68,9 +68,14 @@ struct AttnArgs {
   // attn_fwd_kernel with ONE page only: the page's last row stands for `last_row_copies` identical keys (same K row, same V row):
   // its score gets + ln(copies) / scale, i.e. its softmax weight is multiplied by copies.  0 / 1 = a plain row.
   int last_row_copies;
-  // attn_w64_kernel, optional: three device counters {blocks run, blocks whose FAST pass failed and were redone by the GENERAL pass,
-  // WAVES (64 query rows) that held a failing row themselves} (how data-dependent is the kernel's time on THIS input? -- bench.py --heavy-tail)
+  // attn_w64_kernel, optional: four device counters {blocks run, blocks whose FAST pass failed and were redone by the GENERAL pass,
+  // WAVES (64 query rows) that held a failing row themselves, blocks sent straight to the GENERAL pass by their history byte}
+  // (how data-dependent is the kernel's time on THIS input? -- bench.py --heavy-tail)
   unsigned long long* redo_stats;
+  // attn_w64_kernel, optional: one byte per (head, 256-row query block, split part): [H * ceil(Lq / 256) * 4], carried by the caller
+  // from one launch to the next launch of the same attention (same layer, CFG branch and stage shape); zero = no history.  A block
+  // whose FAST pass failed last time starts in the GENERAL pass (attn_w64.hip).  nullptr: every block tries FAST (stateless).
+  unsigned char* history;
 };
 // Work item `local` of XCD `xcd` -> (head, query block) for attn_w64_kernel / attn_merge_kernel (the hardware deals workgroups
 // round-robin to the 8 XCDs: blockIdx & 7).  H % 8 == 0: XCD x owns heads x, x+8, ...; any other head count (Wan 1.3B: 12):
@@ -146,6 +151,12 @@ hipError_t mmpl_launch_add(bf16_t* a, const bf16_t* b, size_t n, hipStream_t s);
 hipError_t mmpl_launch_unpatchify(const bf16_t* y, int ldy, bf16_t* out, int F, int C, int h, int w, hipStream_t s);
 // sinusoidal timestep embedding (fp64 math): t[F] fp32 -> out[F, freq_dim] bf16 ([cos | sin])
 hipError_t mmpl_launch_zero_ints(int* p, int n, hipStream_t s);
+// MMPL_CHECK_SHARE=1 (api.hip: the guard of mmpl_dit_forward's share_in promise).  chk: 5 device uint64 = {producer fingerprint[2],
+// consumer fingerprint[2], mismatch count}; a fingerprint is accumulated over a list of equally sized pages (K pages, then V pages).
+struct PageList { const void* p[MMPL_MAX_PAGES]; int n; };
+hipError_t mmpl_launch_share_check_zero(unsigned long long* chk, int which, hipStream_t s);
+hipError_t mmpl_launch_pages_fingerprint(const PageList& pl, size_t bytes_per_page, unsigned long long* chk, int which, hipStream_t s);
+hipError_t mmpl_launch_share_check_compare(unsigned long long* chk, hipStream_t s);
 // flags[r] = (row r of x[rows, d] == row rows - 1, bitwise)
 hipError_t mmpl_launch_rows_equal_last(const bf16_t* x, int ld, int rows, int d, int* flags, hipStream_t s);
 hipError_t mmpl_launch_sinusoid(const float* t, bf16_t* out, int F, int freq_dim, hipStream_t s);

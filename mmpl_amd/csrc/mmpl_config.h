@@ -16,6 +16,8 @@
 //   MMPL_GEMM_V8=0|1             large GEMMs never / always on gemm_bf16_v8_kernel (default: the launcher's per-shape choice)
 //   MMPL_VAE_NO_FUSE_NORM=1      RMS_norm + SiLU of the 96-channel layers as its own pass instead of the producing conv's epilogue
 //   MMPL_LN_PIPELINE_MIN_ROWS=n  rows from which LayerNorm takes the pipelined kernel (default 16384; 0 = always, a huge n = never)
+//   MMPL_CHECK_SHARE=1           debug guard of mmpl_dit_forward's share_in promise: the producer (share_out) and the consumer (share_in)
+//                                fingerprint their visible layer-0 K / V on the device; a mismatch is an error (include/mmpl_hip.h)
 #pragma once
 
 struct MmplRuntimeConfig {
@@ -26,5 +28,6 @@ struct MmplRuntimeConfig {
   int gemm_v8;         // -1 = launcher's choice, 0 / 1 = never / always the one-wave-per-SIMD kernel for the main launch
   bool vae_no_fuse_norm;
   int ln_pipeline_min_rows;
+  bool check_share;
 };
 const MmplRuntimeConfig& mmpl_config();

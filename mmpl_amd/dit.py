@@ -40,6 +40,8 @@ class DitEngine:
     def __init__(self, cfg: dict, lat_h: int, lat_w: int, device="cuda:0", max_frames: int = 7):
         self.cfg = dict(cfg)
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:      # 'cuda' != 'cuda:0' for torch.device.__eq__: normalise once
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.lat_h, self.lat_w = lat_h, lat_w
         self.S = (lat_h // 2) * (lat_w // 2)
         self.dim, self.L = cfg["dim"], cfg["num_layers"]
@@ -69,7 +71,7 @@ class DitEngine:
         self._i2v_w: Optional[dict] = None                 # img_emb + per-layer k_img / v_img / norm_k_img (model_type 'i2v')
         self._img_kv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
         self._attn_stats: Optional[torch.Tensor] = None
-        self._warm = False
+        self._warm = set()                                 # stage shapes (n_frames) that ran eagerly once: capture()
 
     def __del__(self):
         try:
@@ -122,14 +124,14 @@ class DitEngine:
 
     # ------------------------------------------------------------------ diagnostics
     def enable_attn_stats(self) -> torch.Tensor:
-        """Count the self-attention kernel's query blocks and how many of them the max-free FAST softmax pass could not hold
-        (redone by the GENERAL pass): int64 [3] on the device = {blocks, blocks redone, waves (64 rows) that held a failing row},
-        incremented by every later forward.
+        """Count the self-attention kernel's query blocks and what its data-dependent softmax passes did with them: int64 [4] on the
+        device = {blocks, blocks whose max-free FAST pass failed and that the GENERAL pass redid (both paid), waves (64 rows) that
+        held a failing row, blocks their history byte sent straight to the GENERAL pass}, incremented by every later forward.
         The counter's address is a kernel argument: a hipGraph captured while stats are on keeps counting on every replay
         whatever `disable_attn_stats` says later, and one captured while they are off never counts.  One atomic per 256-row
         block; `bench.py` switches it on for its diagnostic modes only."""
         if self._attn_stats is None:
-            self._attn_stats = torch.zeros(3, dtype=torch.int64, device=self.device)
+            self._attn_stats = torch.zeros(4, dtype=torch.int64, device=self.device)
         _lib.check(self._lib.mmpl_dit_set_attn_stats(self._h, _lib.ptr(self._attn_stats)), "mmpl_dit_set_attn_stats")
         return self._attn_stats
 
@@ -137,14 +139,29 @@ class DitEngine:
         """Later eager forwards and later captures stop counting (graphs captured before keep their setting)."""
         _lib.check(self._lib.mmpl_dit_set_attn_stats(self._h, None), "mmpl_dit_set_attn_stats")
 
-    def read_attn_stats(self, reset: bool = False) -> Tuple[int, int, int]:
-        """(blocks run, blocks redone, waves that held a failing row) since the counters were last zeroed."""
+    def read_attn_stats(self, reset: bool = False) -> Tuple[int, int, int, int]:
+        """(blocks run, blocks redone, waves that held a failing row, blocks predicted) since the counters were last zeroed."""
         if self._attn_stats is None:
             raise RuntimeError("DitEngine.read_attn_stats: enable_attn_stats() was never called on this engine")
-        blocks, redone, waves = (int(v) for v in self._attn_stats.cpu())
+        blocks, redone, waves, predicted = (int(v) for v in self._attn_stats.cpu())
         if reset:
             self._attn_stats.zero_()
-        return blocks, redone, waves
+        return blocks, redone, waves, predicted
+
+    def new_attn_history(self, n_frames: Optional[int] = None) -> torch.Tensor:
+        """Zeroed history of the self-attention's softmax passes for `forward(attn_history=...)`: one byte per (layer, head, 256-row
+        query block, split part), sized for stages of up to `n_frames` frames (default: the engine's largest).  One buffer per (CFG
+        branch, stage); `zero_()` it when the stage changes (include/mmpl_hip.h)."""
+        n = self._lib.mmpl_dit_attn_history_bytes(self._h, self.max_frames if n_frames is None else n_frames)
+        return torch.zeros(n, dtype=torch.uint8, device=self.device)
+
+    def share_check_failures(self) -> int:
+        """MMPL_CHECK_SHARE=1: share_in forwards since the last call whose layer-0 K / V differed from their share_out forward's
+        (synchronises; 0 when the switch is off)."""
+        n = C.c_longlong(0)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.mmpl_dit_share_check_failures(self._h, C.byref(n), _lib.stream_ptr()), "mmpl_dit_share_check_failures")
+        return n.value
 
     # ------------------------------------------------------------------ caches
     def new_kv_cache(self, n_slots: int = 15) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -240,7 +257,7 @@ class DitEngine:
                 visible_slots: Sequence[int], k_cache: torch.Tensor, v_cache: torch.Tensor, cross_k: torch.Tensor,
                 cross_v: torch.Tensor, out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
                 cross_rows: Optional[int] = None, share_out: Optional[torch.Tensor] = None,
-                share_in: Optional[torch.Tensor] = None) -> torch.Tensor:
+                share_in: Optional[torch.Tensor] = None, attn_history: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x: [nF, in_dim, lat_h, lat_w] bf16 (i2v: x and y concatenated on the channel axis); t: [nF] float32 (device).
         Returns the flow prediction [nF, 16, lat_h, lat_w].
         `cross_rows`: the `CrossKV.rows` that belongs to the CONTENTS of cross_k / cross_v (rows cross_rows .. text_len-1 repeat one
@@ -248,6 +265,9 @@ class DitEngine:
         `share_out` / `share_in` ([nF * S, dim] bf16, see `shared_block0_buffer`): the two branches of classifier-free guidance run
         block 0's self-attention on identical inputs; the first forward leaves x after that residual in `share_out`, the second
         takes it as `share_in` and skips the attention and its output projection (include/mmpl_hip.h; bit-identical).
+        `attn_history` (`new_attn_history()`): what the self-attention's softmax passes did on the previous forward of this (CFG
+        branch, stage); blocks whose FAST pass failed then start in the GENERAL pass.  The output bits then depend on the forwards
+        before (include/mmpl_hip.h); None = stateless.
         `workspace`: a private scratch buffer (>= workspace_bytes(nF)) for a forward that runs concurrently with another
         one on a different stream (cond / uncond); default: the engine's own."""
         nF = x.shape[0]
@@ -257,6 +277,9 @@ class DitEngine:
             raise RuntimeError("DitEngine: an i2v model needs set_image_kv(*precompute_image_context(clip_fea)) before forward")
         for sh in (share_out, share_in):
             assert sh is None or (sh.dtype == torch.bfloat16 and sh.is_contiguous() and sh.numel() >= nF * self.S * self.dim and sh.device == x.device)
+        if attn_history is not None:
+            need = self._lib.mmpl_dit_attn_history_bytes(self._h, nF)
+            assert attn_history.dtype == torch.uint8 and attn_history.is_contiguous() and attn_history.numel() >= need and attn_history.device == x.device
         if out is None:
             out = torch.empty(nF, 16, self.lat_h, self.lat_w, dtype=torch.bfloat16, device=x.device)
         ws = self.workspace(nF) if workspace is None else workspace
@@ -268,12 +291,13 @@ class DitEngine:
                 _lib.ptr(k_cache), _lib.ptr(v_cache), n_slots, _lib.ptr(cross_k), _lib.ptr(cross_v),
                 self.text_len if cross_rows is None else int(cross_rows),
                 None if share_out is None else _lib.ptr(share_out), None if share_in is None else _lib.ptr(share_in),
-                _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "mmpl_dit_forward")
+                None if attn_history is None else _lib.ptr(attn_history), _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "mmpl_dit_forward")
         return out
 
     # ------------------------------------------------------------------ hipGraph
     def capture(self, x: torch.Tensor, t: torch.Tensor, frame_ids, write_slots, visible_slots, k_cache, v_cache, cross_k, cross_v,
-                out: torch.Tensor, pre=None, cross_rows: Optional[int] = None) -> "torch.cuda.CUDAGraph":
+                out: torch.Tensor, pre=None, cross_rows: Optional[int] = None,
+                attn_history: Optional[torch.Tensor] = None) -> "torch.cuda.CUDAGraph":
         """Capture one forward (fixed stage shape, slot table and buffers) into a hipGraph.  The forward is a pure launch
         sequence -- no host sync, no allocation -- so replaying it costs one graph launch instead of ~13 launches per
         layer.  `x`, `t`, `out` and the caches are captured BY ADDRESS: update their contents in place between replays
@@ -281,16 +305,20 @@ class DitEngine:
         `pre`: launches recorded in front of the forward (the i2v model type refreshes the latent channels of its 36-channel
         input buffer there)."""
         self.workspace(x.shape[0])                      # allocate outside the capture
-        if not self._warm:                              # one eager call per engine: lazy kernel attributes are set outside
+        if x.shape[0] not in self._warm:                # one eager call per (engine, stage shape): the kernels a shape selects (pipelined
+            # LayerNorm from 16 384 rows, the v8 GEMM variants, attn_cross_kernel<NT>, the split-KV tail) set their dynamic-LDS
+            # attribute / query their occupancy on first launch -- outside the capture, not inside it
             if pre is not None:
                 pre()
-            self.forward(x, t, frame_ids, write_slots, visible_slots, k_cache, v_cache, cross_k, cross_v, out=out, cross_rows=cross_rows)
-            self._warm = True
+            self.forward(x, t, frame_ids, write_slots, visible_slots, k_cache, v_cache, cross_k, cross_v, out=out, cross_rows=cross_rows,
+                         attn_history=attn_history)
+            self._warm.add(x.shape[0])
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             if pre is not None:
                 pre()
-            self.forward(x, t, frame_ids, write_slots, visible_slots, k_cache, v_cache, cross_k, cross_v, out=out, cross_rows=cross_rows)
+            self.forward(x, t, frame_ids, write_slots, visible_slots, k_cache, v_cache, cross_k, cross_v, out=out, cross_rows=cross_rows,
+                         attn_history=attn_history)
         return g
 

@@ -79,6 +79,11 @@ class CausalFPSInferencePipeline(torch.nn.Module):
         # takes x after that residual from the cond forward instead of recomputing it (mmpl_dit_forward share_out / share_in;
         # bit-identical).  False switches it off.
         self.share_block0 = True
+        # The self-attention kernel's softmax is a max-free FAST pass per 256-row query block plus a GENERAL pass for the blocks it
+        # cannot hold (heavy-tailed scores: large QK-norm gains).  With a history (one byte per layer / head / block, kept with each
+        # branch's KV cache, zeroed per stage) a block that failed on the previous denoise step starts in GENERAL instead of paying for
+        # both.  Exact softmax either way; the bits then depend on the steps before (include/mmpl_hip.h).  False = stateless.
+        self.attn_history = True
         self.cfg_pair = None              # mmpl_amd.handoff.CfgPair: this rank runs only the cond (role 0) / uncond (role 1) branch
 
         # ---- "add new noise on previous frames" schedule (casual_fps_inference.py:93-108); the randint keeps the
@@ -157,6 +162,8 @@ class CausalFPSInferencePipeline(torch.nn.Module):
                     if kv is not None:
                         kv.reset()
             live_kv = [kv for kv in (self.kv_cache_pos, self.kv_cache_neg) if kv is not None]
+            for kv in live_kv:
+                kv.enable_attn_history(self.attn_history)
 
             stages = self.plan.stages
             S = self.frame_seq_length
@@ -250,6 +257,8 @@ class CausalFPSInferencePipeline(torch.nn.Module):
                                     self._forward(latents, d, timestep, kv, cross, frames, o, share_out=share if bi == 0 else None,
                                                   share_in=share if bi == 1 else None)
                             sample_scheduler.step_cfg_table(flow[0], flow[1], latents, timestep)
+                for kv in live_kv:                                            # a new stage: other shapes, other blocks
+                    kv.reset_attn_history()
                 if step_graph is not None:
                     timestep.fill_(float(sample_scheduler.timesteps[0]))
                     for _ in sample_scheduler.timesteps:
@@ -269,6 +278,10 @@ class CausalFPSInferencePipeline(torch.nn.Module):
                         sample_scheduler.step_cfg(flow[0], flow[1], self.args.guidance_scale, latents)
 
                 output[:, frames] = latents
+                bad = self.generator_cond.engine.share_check_failures()       # MMPL_CHECK_SHARE=1 (debug; 0 without it, no sync)
+                if bad:
+                    raise RuntimeError(f"MMPL_CHECK_SHARE: {bad} uncond forward(s) of stage {si} took block 0's self-attention from the cond "
+                                       "forward although the layer-0 K / V of the two caches differ")
                 if si == self.plan.handoff_stage:                             # t2v :380-383, i2v :340-343
                     save_latents = (torch.cat([output[:, :1], latents], dim=1) if self.mode == "t2v"
                                     else torch.cat([output[:, :1], output[:, -2:]], dim=1))

@@ -93,6 +93,20 @@ def dit_forward_flops(cfg: dict, frame_seqlen: int, n_q_frames: int, n_kv_frames
     return L * (2.0 * Lq * (6.0 * d * d + 2.0 * d * f) + 4.0 * Lq * Lkv * d + 4.0 * Lq * text_len * d)
 
 
+def dit_forward_flops_executed(cfg: dict, frame_seqlen: int, n_q_frames: int, n_kv_frames: int, cross_keys: int,
+                               block0_self_attn_shared: bool = False) -> float:
+    """FLOPs of the launches a forward actually issues, where they differ from the reference's algorithmic count
+    (`dit_forward_flops`): the text cross-attention over `cross_keys` keys (the padded tail collapsed: CrossKV.rows + 1 instead of
+    512) and, for the uncond forward of a step whose branches run back to back, no block-0 self-attention and no block-0 output
+    projection (`share_in`).  Both are bit-exact savings; the algorithmic count is what `roofline` and SURVEY.md 8(d) price."""
+    d, f, L = cfg["dim"], cfg["ffn_dim"], cfg["num_layers"]
+    Lq, Lkv = n_q_frames * frame_seqlen, n_kv_frames * frame_seqlen
+    fl = L * (2.0 * Lq * (6.0 * d * d + 2.0 * d * f) + 4.0 * Lq * Lkv * d + 4.0 * Lq * cross_keys * d)
+    if block0_self_attn_shared:
+        fl -= 4.0 * Lq * Lkv * d + 2.0 * Lq * d * d
+    return fl
+
+
 # (query frames, attended frames) per T2V stage, first chunk (SURVEY.md Appendix A)
 T2V_STAGE_SHAPES = [(2, 2), (7, 9), (6, 13), (6, 21)]
 # I2V denoise stages s1..s4 (s0 = the image latent, refresh pass only; frames 19, 20 stay visible in s3): SURVEY.md App. A

@@ -38,6 +38,9 @@ class KVCache(list):
         self.engine = engine
         self.k_all, self.v_all = engine.new_kv_cache(n_slots)
         self.vis: List[int] = []          # token offsets, shared by every layer (the reference keeps L identical copies)
+        # what the self-attention's softmax passes did on this branch's previous forward (DitEngine.new_attn_history): travels with
+        # the cache because it is per CFG branch; the pipeline zeroes it at every stage boundary.  None = stateless attention.
+        self.attn_history: Optional[torch.Tensor] = None
         H = engine.cfg["num_heads"]
         for l in range(engine.L):
             self.append({"k": self.k_all[l].view(1, -1, H, 128), "v": self.v_all[l].view(1, -1, H, 128),
@@ -47,6 +50,17 @@ class KVCache(list):
 
     def reset(self):
         self.vis.clear()
+        self.reset_attn_history()
+
+    def enable_attn_history(self, on: bool = True):
+        if on and self.attn_history is None:
+            self.attn_history = self.engine.new_attn_history()
+        elif not on:
+            self.attn_history = None
+
+    def reset_attn_history(self):
+        if self.attn_history is not None:
+            self.attn_history.zero_()
 
 
 class CrossAttnCache(list):
@@ -182,7 +196,8 @@ class WanFPSWrapper(torch.nn.Module):
             pre = lambda: x[:, :16].copy_(lat)
         g = self.engine.capture(x, timestep.view(-1), frames, StagePlan.write_slots(frames),
                                 [slot_of(o // S) for o in vis], kv_cache.k_all, kv_cache.v_all, crossattn_cache.k_all,
-                                crossattn_cache.v_all, out[0], pre=pre, cross_rows=crossattn_cache.rows)
+                                crossattn_cache.v_all, out[0], pre=pre, cross_rows=crossattn_cache.rows,
+                                attn_history=kv_cache.attn_history)
         return g if ys is None else _HeldGraph(g, x)
 
     def forward(self, noisy_image_or_video: torch.Tensor, conditional_dict: dict, timestep: torch.Tensor,
@@ -215,7 +230,7 @@ class WanFPSWrapper(torch.nn.Module):
         flow = self.engine.forward(x, t, frames, StagePlan.write_slots(frames), [slot_of(o // S) for o in vis],
                                    kv_cache.k_all, kv_cache.v_all, crossattn_cache.k_all, crossattn_cache.v_all,
                                    out=None if out is None else out[0], cross_rows=crossattn_cache.rows, workspace=workspace,
-                                   share_out=share_out, share_in=share_in)
+                                   share_out=share_out, share_in=share_in, attn_history=kv_cache.attn_history)
         flow_pred = flow.unsqueeze(0)
         pred_x0 = None
         if return_x0:                                                     # wan_wrapper.py:373-397 (unused by the pipeline)

@@ -139,36 +139,10 @@ def bench(variants, iters=3, rounds=3, stages=("s0", "s1", "s2", "s3")):
         print(line + "  | best " + " ".join(f"v{v} {best[v]:.1f}" for v in variants) + diffs, flush=True)
 
 
-def cycles(stage="s3"):
-    """needs a -DW64_ABL=16|... build: the kernel leaves per-wave loop cycle counts in o instead of the output"""
-    H, S, d = 40, 3600, 5120
-    nq, npg = {"s0": (2, 2), "s1": (7, 9), "s2": (6, 13), "s3": (6, 21)}[stage]
-    Lq = nq * S
-    kc = torch.randn(npg * S, d, device=dev).to(BF)
-    vc = torch.randn(npg * S, d, device=dev).to(BF)
-    qp = (torch.randn(Lq, 3 * d, device=dev) * CQ).to(BF)
-    kp = (C.c_void_p * npg)(*[kc[i * S:].data_ptr() for i in range(npg)])
-    vp = (C.c_void_p * npg)(*[vc[i * S:].data_ptr() for i in range(npg)])
-    o = torch.zeros(Lq, d, device=dev, dtype=BF)
-    for _ in range(3):
-        run(4, qp, 3 * d, o, d, kp, vp, npg, S, Lq, H, ws=False)
-    torch.cuda.synchronize()
-    n_blocks = (Lq // 256) * H               # full query blocks only (the main round), 4 waves each
-    t = o.view(-1).view(torch.float32)[: n_blocks * 8].view(-1, 2).double()
-    t = t[t[:, 1] > 0]
-    per_tile = (t[:, 0] / t[:, 1])
-    print(f"cycles {stage}: waves {len(per_tile)} tiles/wave {t[0, 1].item():.0f}  cycles/tile mean {per_tile.mean().item():.1f} "
-          f"min {per_tile.min().item():.1f} p50 {per_tile.median().item():.1f} max {per_tile.max().item():.1f}  "
-          f"-> {per_tile.mean().item() / 64:.2f} cycles per MFMA", flush=True)
-
-
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "check"
     variants = [int(x) for x in sys.argv[2:] if x.isdigit()] or [1, 4]
     stages = [x.split("=")[1].split(",") for x in sys.argv[2:] if x.startswith("stages=")]
-    if what == "cycles":
-        cycles(stages[0][0] if stages else "s3")
-        sys.exit(0)
     if what == "check":
         sys.exit(1 if check(variants) else 0)
     bench(variants, stages=stages[0] if stages else ("s0", "s1", "s2", "s3"))

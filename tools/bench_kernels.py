@@ -141,7 +141,7 @@ def bench_gemm_ref(iters):
 
 
 def gemm_phases(epi=3):
-    """needs a -DGEMM6_TIMING=1 build (tools/gemm6_phases2.sh): per-wave { prologue, k loop, epilogue } cycles written over the output"""
+    """needs a -DMMPL_DEV_ABLATIONS -DGEMM6_TIMING=1 build (tools/r06_gpu.sh gemmphases): per-wave { prologue, k loop, epilogue } cycles written over the output"""
     M, N, K = (int(v) for v in os.environ.get("BENCH_PHASE_SHAPE", "25200:5120:5120").split(":"))
     A = torch.randn(M, K, device=dev).to(BF)
     W = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(BF)

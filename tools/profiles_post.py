@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Post-processes what tools/r03_profiles.sh collected: python3 tools/r03_profiles_post.py <dir> <tag>
+"""Post-processes what tools/r06_gpu.sh (steps stats / hbm / busy) collected: python3 tools/profiles_post.py <dir> <tag>
    -> <dir>/<tag>_kernel_stats.csv, <dir>/<tag>_pmc_attention_hbm.json, <dir>/<tag>_pmc_hbm_per_kernel.md, <dir>/<tag>_pmc_mfma_busy.md"""
 import collections
 import csv
@@ -60,7 +60,7 @@ if len(vals) == 2:
                "hbm_read_bytes_per_op": rd, "hbm_write_bytes_per_op": wr, "mean_hbm_bytes_per_op": rd + wr,
                "algorithmic_bytes_per_op": algo, "ratio": (rd + wr) / algo}, open(os.path.join(d, f"{tag}_pmc_attention_hbm.json"), "w"), indent=1)
     # bench.py reads roofline.traffic from the file THIS names (copy both into profiles/): no sorted glob
-    json.dump({"attention_traffic_file": f"{tag}_pmc_attention_hbm.json", "written_by": "tools/r03_profiles_post.py"},
+    json.dump({"attention_traffic_file": f"{tag}_pmc_attention_hbm.json", "written_by": "tools/profiles_post.py"},
               open(os.path.join(d, "PMC_TRAFFIC.json"), "w"))
 
 # ---- HBM traffic per launch of EVERY kernel (the same two passes): what the memory-bound passes really move
@@ -121,4 +121,27 @@ if fs:
         lines.append(f"| `{k[:70]}` | {cnt[k]} | {100 * a['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc):.1f} % | {cyc / dur[k]:.2f} | "
                      f"{a['SQ_WAVE_CYCLES'] * 4 / 1024 / cyc:.2f} |")
     open(os.path.join(d, f"{tag}_pmc_mfma_busy.md"), "w").write("\n".join(lines) + "\n")
+# ---- L2 (TCC) hits / misses and fabric reads per launch of the block GEMMs (tools/r06_gpu.sh tcc: bench_kernels.py gemm, one launch per shape)
+fs = glob.glob(os.path.join(d, "tcc_*", "**", "*counter_collection.csv"), recursive=True)
+if fs:
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    nlaunch = collections.defaultdict(lambda: collections.defaultdict(set))
+    for f in fs:
+        for r in csv.DictReader(open(f)):
+            if "gemm_" not in r["Kernel_Name"]:
+                continue
+            key = (short(r["Kernel_Name"])[:60], r["Grid_Size"])
+            acc[key][r["Counter_Name"]] += float(r["Counter_Value"])
+            nlaunch[key][r["Counter_Name"]].add(r["Dispatch_Id"])
+    lines = [f"# {tag} PMC: L2 (TCC) behaviour of the 14B / 720p block GEMMs, per launch", "",
+             "`rocprofv3 --kernel-trace --pmc <TCC_HIT_sum TCC_MISS_sum | TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum | FETCH_SIZE>` (separate passes) "
+             "`-- python3 tools/bench_kernels.py gemm --iters 1` (warm-up launches included in the mean); FETCH_SIZE bytes = KiB x 1024 x 2 on gfx950.", "",
+             "| kernel | grid | launches | L2 hits | L2 misses | hit rate | fabric read requests (32 B of them) | fabric read GB |", "|---|---|---|---|---|---|---|---|"]
+    for key in sorted(acc, key=lambda k: -acc[k].get("TCC_HIT_sum", 0)):
+        a = acc[key]
+        per = lambda c: a[c] / max(len(nlaunch[key][c]), 1) if c in a else float("nan")
+        hit, miss = per("TCC_HIT_sum"), per("TCC_MISS_sum")
+        lines.append(f"| `{key[0]}` | {key[1]} | {max((len(v) for v in nlaunch[key].values()), default=0)} | {hit:.4g} | {miss:.4g} | "
+                     f"{100 * hit / max(hit + miss, 1):.1f} % | {per('TCC_EA0_RDREQ_sum'):.4g} ({per('TCC_EA0_RDREQ_32B_sum'):.4g}) | {per('FETCH_SIZE') * 2048 / 1e9:.3f} |")
+    open(os.path.join(d, f"{tag}_pmc_gemm_l2.md"), "w").write("\n".join(lines) + "\n")
 print("post-processing done:", sorted(os.path.basename(p) for p in glob.glob(os.path.join(d, f"{tag}_*"))))
