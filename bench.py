@@ -374,6 +374,7 @@ def run_wavefront(args, dist, rank, world, dev, gloo):
                                      (", RCCL p2p anchor hand-off behind a host-side ready handshake" if world > 1 and not gloo else
                                       (", hand-off staged through the host (gloo)" if world > 1 else ", sequential chain on one rank"))},
            "wall_s": wall, "chunks": C_, "lanes": n_lanes,
+           "wall_scale_to_50_steps": to_50,                 # `value` = 21 C / (wall x this); 1.0 at --sampling-steps 50
            "value_modelled": modelled,
            "value_modelled_note": "min(lanes, chunk_s / anchor_s) * 21 / chunk_s with this run's mean chunk and anchor-stage times of chunks >= 2 "
                                   "(the occupancy model the K-steps N > 1 line prints)",
@@ -382,7 +383,7 @@ def run_wavefront(args, dist, rank, world, dev, gloo):
            "handoff_latency_s": {str(c): v for c, v in sorted(lat_ho.items())},
            "handoff_latency_note": "recv complete - max(anchors available on the producer, consumer ready): RCCL p2p + header (+ host staging under gloo)",
            "producer_waited_for_consumer_s": {str(c): v for c, v in sorted(wait_ho.items())},
-           "achieved_pflops_all_gpus_upper_bound": flops / wall / 1e15}
+           "achieved_pflops_all_gpus": flops / wall / 1e15}
     if not args.no_cpu_baseline:
         try:
             res["cpu_baseline"] = cpu_baseline(cfg, lat_h, lat_w, T2V_STAGE_SHAPES, args.cpu_budget_s)

@@ -539,6 +539,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     if (__any(bad) && lane == 0) atomicAdd(a.redo_stats + 2, 1ull);        // waves (64 query rows) that held a failing row themselves
   }
+  if (redo_block) w64_pass<1>(k);
+  // The byte is rewritten only HERE: every wave of the block has passed a barrier since it read it (the vote's, or the GENERAL pass's
+  // own), so no late wave can see the new value and take the other branch (a countdown going 2 -> 1 flips the decision).
   if (hist && tid == 0) {
     int ns;
     if (!try_fast) ns = hstate - 1;
@@ -549,7 +552,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     *hist = (unsigned char)ns;
   }
-  if (redo_block) w64_pass<1>(k);
 
   // ---- epilogue: lane (q = l31, hi) holds O_X[q][32*nb + 8*g + 4*hi + {0..3}] in a[64 X + 16 nb + 4 g ..+3]
 #pragma unroll

@@ -45,7 +45,8 @@
 #endif
 // GEMM6_ABL (results are garbage): 1 = every block's LDS-DMA reads operand tile (0, 0): same instruction stream and LDS traffic, every
 // fetch an L2 hit -> what the loop costs without fabric / HBM latency; 2 = no epilogue at all (what a perfectly overlapped epilogue
-// would leave); 4 = no LDS-DMA in the k loop; 8 = the whole staged epilogue except its global stores
+// would leave); 4 = no LDS-DMA in the k loop; 8 = the whole staged epilogue except its global stores; 16 = no residual loads in the
+// staged epilogue (a constant instead: the upper bound of what issuing them under the last k-tile could hide)
 #ifndef GEMM6_ABL
 #define GEMM6_ABL 0
 #endif

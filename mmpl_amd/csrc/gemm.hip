@@ -440,7 +440,9 @@ MMPL_DEV void epi_load_res(const GemmArgs& g, EpiIn& in, int mw, int nw, int lan
 #pragma unroll
     for (int u = U0; u < U1; ++u) {
       const int m = mw + 8 * u + erow;
-      if (n_ok && m < g.M) {
+      if ((GEMM6_ABL & 16) && g.M >= 0) {                              // dev mock (results are garbage): no residual loads at all -- the upper
+        in.res8[u] = uint4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};      // bound of what hiding them under the k loop can buy
+      } else if (n_ok && m < g.M) {
         const u32x4* rp = reinterpret_cast<const u32x4*>(g.res + (size_t)m * g.ldres + n);
         const u32x4 rv = GEMM6_RESLD ? __builtin_nontemporal_load(rp) : *rp;
         in.res8[u] = uint4{rv[0], rv[1], rv[2], rv[3]};

@@ -85,9 +85,15 @@ class CfgPair:
         self.device = torch.device("cpu") if self.backend == "gloo" else torch.device(device)
 
     @classmethod
-    def build(cls, world: int, device, cfg_split: bool = True):
-        """Collective over ALL ranks (every rank creates every group, as torch.distributed requires).
-        Returns (pair or None, lane_heads_group, layout)."""
+    def build(cls, world: int, device, cfg_split: bool = True, warm: bool = True):
+        """Collective over ALL ranks (every rank creates every group, in the same order, as torch.distributed requires -- with the
+        nccl backend and `init_process_group(device_id=...)` a sub-group is an `ncclCommSplit` of the world communicator, itself a
+        collective over the parent).  Returns (pair or None, lane_heads_group, layout).
+        warm: every member then runs one tiny all-reduce per group IN CREATION ORDER (its pair group, then -- lane heads only -- the
+        heads group): an RCCL communicator that was not created eagerly is created by its first collective, a blocking rendezvous of
+        all its members; doing it here, in one fixed order on every rank, keeps it out of the data path, where the lane heads' first
+        use of the heads group (an anchor hand-off on the side stream) and of the pair group (a flow all-gather on the compute stream)
+        would otherwise come in a data-dependent order."""
         import torch.distributed as dist
         lay = wavefront_layout(world, cfg_split)
         me = dist.get_rank()
@@ -98,6 +104,12 @@ class CfgPair:
                 if me in ranks:
                     pair = cls(ranks, g, device)
         heads = dist.new_group(lay["heads"]) if cfg_split else None
+        if warm and cfg_split:
+            one = torch.ones(1, device=pair.device)
+            dist.all_reduce(one, group=pair.group)
+            if me in lay["heads"]:
+                dist.all_reduce(one, group=heads)
+            assert float(one) == (2.0 * len(lay["heads"]) if me in lay["heads"] else 2.0), float(one)
         return pair, heads, lay
 
     def exchange(self, mine: torch.Tensor, both: torch.Tensor) -> torch.Tensor:

@@ -37,7 +37,7 @@ def _denoise(lat, steps, flows):
 def _worker(rank, world, port, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=240))
     try:
         pair, heads, lay = CfgPair.build(world, "cpu", cfg_split=True)
         lane = lay["lane_of"][rank]
@@ -99,7 +99,7 @@ def test_cfg_pairs_two_lanes(tmp_path):
 def _wavefront_worker(rank, world, port, out_path, n_chunks):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=240))
     try:
         from mmpl_amd.handoff import run_chunk_wavefront
         pair, heads, lay = CfgPair.build(world, "cpu", cfg_split=True)
@@ -144,3 +144,33 @@ def test_wavefront_with_cfg_pairs_four_ranks(tmp_path):
         prev = v
     got = [float(t.float().mean()) for t in r[0]["res"]]
     assert got == want
+
+
+@pytest.mark.parametrize("n_chunks", [8, 9])
+def test_wavefront_with_cfg_pairs_eight_ranks(tmp_path, n_chunks):
+    """BASELINE configs[4]'s layout on CPU: world 8 = 4 chunk lanes x (cond, uncond) -- 4 pair groups + the 4-rank heads group + the
+    world group + their gloo control groups, all built by CfgPair.build in every process.  8 chunks (two per lane) and 9 (chunk 8 wraps
+    around onto lane 0 while it may still be busy with chunk 4: the reference's round-robin with a busy flag,
+    Wan_fps_inference_parallel_4gpu_5-60s.py:188-381).  Every rank exits (mp.spawn joins all eight), the uncond partner of every lane
+    follows its head chunk by chunk, the hand-offs arrive in dependency order and only rank 0 gathers."""
+    world, n_lanes = 8, 4
+    lay = wavefront_layout(world, True)
+    assert lay["lanes"] == [[0, 1], [2, 3], [4, 5], [6, 7]] and lay["heads"] == [0, 2, 4, 6]
+    out = str(tmp_path / "w8")
+    mp.spawn(_wavefront_worker, args=(world, _free_port(), out, n_chunks), nprocs=world, join=True)
+    r = [torch.load(f"{out}.{k}") for k in range(world)]
+    for lane in range(n_lanes):
+        head, partner = r[2 * lane], r[2 * lane + 1]
+        assert [c for c, _ in head["log"]] == list(range(lane, n_chunks, n_lanes))          # chunk c on lane c mod 4, in order
+        assert partner["log"] == head["log"]                                                  # same chunks, same initial latents
+        assert (head["res"] is not None) == (lane == 0) and partner["res"] is None
+    # the dependency chain ran through all four lanes and wrapped around: chunk c's anchors = c + 1 + mean(initial from chunk c - 1)
+    want, prev = [], None
+    for c in range(n_chunks):
+        v = float(torch.tensor(float(c + 1) + (0.0 if prev is None else prev)).to(torch.bfloat16))
+        want.append(v)
+        prev = v
+    assert len(r[0]["res"]) == n_chunks and [float(t.float().mean()) for t in r[0]["res"]] == want
+    # ... and what every consumer was handed is exactly its predecessor's value (None only for chunk 0)
+    seen = {c: init for k in range(0, world, 2) for c, init in r[k]["log"]}
+    assert seen[0] is None and all(seen[c] == want[c - 1] for c in range(1, n_chunks))

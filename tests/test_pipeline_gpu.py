@@ -17,18 +17,18 @@ LAT = (16, 24)
 TRAJ_TOL = 1.5e-2
 
 
-def _setup(mode="t2v", steps=2, with_vae=False, lat=LAT):
+def _setup(mode="t2v", steps=2, with_vae=False, lat=LAT, cfg_name="tiny", weight_seed=2, ctx_seeds=(21, 22), n_valid=(40, 12)):
     from mmpl_amd.geometry import Geometry
     from mmpl_amd.pipeline import CausalFPSInferencePipeline
     from mmpl_amd.synthetic import WAN_CONFIGS, dit_state_dict, philox_normal, vae_state_dict
     from mmpl_amd.wan_wrapper import WanFPSWrapper, WanTextEncoder, WanVAEWrapper
-    cfg = WAN_CONFIGS["tiny"]
+    cfg = WAN_CONFIGS[cfg_name]
     geo = Geometry(*lat)
-    sd = dit_state_dict(cfg, seed=2)
+    sd = dit_state_dict(cfg, seed=weight_seed)
     gen = WanFPSWrapper(is_causal=True, timestep_shift=5.0, model_config=cfg, geometry=geo, device="cuda:0")
     gen.load_state_dict({"model." + k: v for k, v in sd.items()})          # MMPL checkpoint key style
     ctx = {}
-    for name, seed, nv in (("pos", 21, 40), ("neg", 22, 12)):
+    for name, seed, nv in (("pos", ctx_seeds[0], n_valid[0]), ("neg", ctx_seeds[1], n_valid[1])):
         c = philox_normal([1, 512, cfg["text_dim"]], seed)
         c[:, nv:] = 0
         ctx[name] = c

@@ -25,10 +25,10 @@ pytestmark = pytest.mark.gpu
 H, Wd = 60, 104
 
 
-def _inputs(lat, noise_seed=23):
+def _inputs(lat, noise_seed=23, renoise_seed_base=100):
     from mmpl_amd.synthetic import philox_normal
     noise = philox_normal([1, 21, 16, *lat], noise_seed)
-    renoise = {f: philox_normal([1, 16, *lat], 100 + f) for f in (4, 9, 13, 18)}
+    renoise = {f: philox_normal([1, 16, *lat], renoise_seed_base + f) for f in (4, 9, 13, 18)}
     return noise, renoise
 
 
@@ -187,3 +187,84 @@ def test_i2v_chunk_vs_reference_fixture_directly(steps, n_init):
           f"(bound {bound:.2e}; the oracle measured {e['oracle_out']:.3e}); vs the reference's CPU-semantics run {e_cpu:.3e}")
     assert torch.equal(lat[:, :n_init], initial) and hand.shape == (1, 3, 16, H, Wd)
     assert e_out <= bound and e_hand <= bound
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The same statement at realistic DEPTH.  Per forward the HIP-vs-reference distance is ~5 x larger at 30 / 40
+# layers than on the 2-layer tiny model (1.25-1.5e-2 vs 2.2-2.7e-3, tests/test_fullsize_gpu.py), and how 50 steps x CFG 5 compound a
+# per-forward difference depends on the depth.  Two ends: (a) an 8-layer model against a file the REAL reference produced, (b) the
+# full 30-layer Wan 1.3B at 480p (BASELINE configs[1]) against the reference's algorithm executed by PyTorch on the device.
+def test_t2v_chunk_50_steps_deeper_model_vs_reference_fixture():
+    """408 forwards on WAN_CONFIGS["deep"] (8 layers, dim 512, 4 heads) at 60x104 against tests/golden/chunk_t2v_deep_50.pt: the REAL
+    reference (its model, its unedited FlowUniPCMultistepScheduler.step) under its native platform's scalar semantics (`_GpuScalar`),
+    make_golden.py chunk50_deep:gpu.  Bound: 2 x that model's own K/V-order noise over the trajectory (chunk50_deep:perm: the same
+    reference run with only its self-attention's K/V gather order reversed).  Also printed: the distance to the reference's CPU-semantics
+    and fp32 runs of the same model, when those runs are in the file."""
+    import os
+    from tests.test_pipeline_gpu import _setup
+    path = f"{GOLDEN}/chunk_t2v_deep_50.pt"
+    assert os.path.exists(path), "tests/golden/chunk_t2v_deep_50.pt missing (python tests/golden/make_golden.py chunk50_deep:gpu chunk50_deep:perm)"
+    fx = torch.load(path)
+    m, nf = fx["meta"], fx["noise_floor"]
+    assert "REAL reference" in fx["produced_by"] and m["steps"] == 50 and m["cfg"] == "deep"
+    assert "gpu_out_strided" in fx and "order_out" in nf, "the fixture needs the gpu and perm runs"
+    pipe, sd, _, cfg, ctx = _setup("t2v", steps=50, lat=(H, Wd), cfg_name=m["cfg"], weight_seed=m["weight_seed"], ctx_seeds=m["ctx_seeds"], n_valid=m["n_valid"])
+    assert cfg["num_layers"] == 8 and pipe.sampling_steps == 50
+    noise, renoise = _inputs((H, Wd), m["noise_seed"], m["renoise_seed_base"])
+    lat, hand = _hip_chunk(pipe, noise, renoise)
+    e, eh = rel_l2(lat[..., ::2, ::2], fx["gpu_out_strided"]), rel_l2(hand[..., ::3, ::3], fx["gpu_handoff_strided"])
+    extra = ""
+    if "out_strided" in fx:
+        extra += f"; vs the reference's CPU-semantics run {rel_l2(lat[..., ::2, ::2], fx['out_strided']):.3e} (that run vs the GPU-semantics one: {nf['gpu_vs_cpu_semantics_out']:.3e})"
+    if "out_f32_strided" in fx:
+        extra += f"; vs the reference's fp32 run {rel_l2(lat[..., ::2, ::2], fx['out_f32_strided']):.3e} (the reference's own bf16-vs-fp32: {nf.get('gpu_vs_f32_out', float('nan')):.3e})"
+    print(f"408 forwards at 60x104 on the 8-layer model: HIP vs the reference under GPU scalar semantics: latents {e:.3e} hand-off {eh:.3e} "
+          f"(bound 2 x the reference's K/V-order noise = {2 * nf['order_out']:.3e} / {2 * nf['order_handoff']:.3e}){extra}")
+    assert torch.isfinite(lat.float()).all()
+    assert e <= 2 * nf["order_out"] and eh <= 2 * nf["order_handoff"]
+
+
+def test_t2v_chunk_full_size_1p3B_480p_vs_reference_algorithm_on_the_device():
+    """BASELINE configs[1] end to end: Wan2.1-T2V-1.3B (all 30 layers, dim 1536, 12 heads), 480p (60x104), a whole first chunk at 10 UniPC
+    steps per stage = 4 x (10 x 2 + 2) = 88 forwards with CFG 5, step hipGraphs on -- the HIP pipeline against the reference's stage loop
+    (casual_fps_inference.py:250-403, fm_solvers_unipc.py:655-739) as restated by the oracle and executed by PyTorch ON THE DEVICE
+    (tools/traj_executor_floor.py at full size).  Bound = 2 x the device oracle's own K/V-order noise, measured here: the same oracle
+    run with only the frame order of the gathered K / V reversed (the reference's order is `list(set(...))`, i.e. unspecified,
+    causal_fps_model.py:219)."""
+    from mmpl_amd.synthetic import dit_state_dict, philox_normal
+    from oracle import stage_ref
+    from oracle import wan_dit_ref as W
+    from tests.test_pipeline_gpu import _setup
+    steps, S = 10, (H // 2) * (Wd // 2)
+    pipe, sd, _, cfg, ctx = _setup("t2v", steps=steps, lat=(H, Wd), cfg_name="1.3B", weight_seed=5, ctx_seeds=(51, 52), n_valid=(48, 10))
+    assert cfg["num_layers"] == 30 and cfg["dim"] == 1536 and pipe.sampling_steps == steps
+    noise, renoise = _inputs((H, Wd), 53, 300)
+    lat, hand = _hip_chunk(pipe, noise, renoise)
+    del pipe
+    torch.cuda.empty_cache()
+    dev = "cuda:0"
+    sd_d = {k: v.to(dev) for k, v in sd.items()}
+    ctxs = [ctx["pos"][0].to(dev), ctx["neg"][0].to(dev)]
+
+    def reversed_frames(q, k, v):
+        if k.shape[1] % S:                               # the text cross-attention (512 keys) goes through the same hook: unchanged
+            return W.sdpa(q, k, v)
+        n = k.shape[1] // S
+        idx = torch.arange(n * S, device=k.device).view(n, S).flip(0).reshape(-1)
+        return W.sdpa(q, k[:, idx], v[:, idx])
+
+    outs = []
+    for attn_fn in (W.sdpa, reversed_frames):
+        with torch.device(dev):
+            o, h, _ = stage_ref.run_chunk(sd_d, W.DitCfg(**cfg), noise.to(dev), ctxs[0], ctxs[1], {k: v.to(dev) for k, v in renoise.items()}, None, "t2v",
+                                          5.0, steps, 5.0, attn_fn=attn_fn)
+        torch.cuda.synchronize()
+        outs.append((o.cpu(), h.cpu()))
+    (o_out, o_hand), (p_out, p_hand) = outs
+    order, order_h = rel_l2(p_out, o_out), rel_l2(p_hand, o_hand)
+    e, eh = rel_l2(lat, o_out), rel_l2(hand, o_hand)
+    print(f"Wan 1.3B / 480p, all 30 layers, 88 forwards (10 steps x CFG 5 x 4 stages + refresh): HIP vs the reference's algorithm on the device: "
+          f"latents {e:.3e} hand-off {eh:.3e}; that executor vs itself with the K/V frame order reversed: {order:.3e} / {order_h:.3e} "
+          f"(bound = 2 x); latents rms {o_out.float().pow(2).mean().sqrt().item():.3f}")
+    assert torch.isfinite(lat.float()).all()
+    assert e <= 2 * order and eh <= 2 * order_h
