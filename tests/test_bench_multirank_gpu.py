@@ -53,7 +53,7 @@ def test_default_two_rank_line_is_a_measured_wavefront():
     assert 2 <= k <= 50 and r["value_modelled"] > 0 and r["ms_per_step"] > 0
     if k < 50:
         assert abs(r["value_shortened_run"] - 21.0 * 4 / r["wall_s"]) < 1e-9 and "value_scaling" in r
-        assert abs(r["wall_scale_to_50_steps"] - _scale_to_50(k, 4)) < 1e-9 and r["wall_scale_to_50_steps"] <= 102.0 / (2 * k + 2) + 1e-9
+        assert abs(r["wall_scale_to_50_steps"] - _scale_to_50(k, 4)) < 1e-9 and 1.0 < r["wall_scale_to_50_steps"] <= 100.0 / (2 * k)
         assert abs(r["value"] - r["value_shortened_run"] / r["wall_scale_to_50_steps"]) < 1e-9
     else:
         assert abs(r["value"] - 21.0 * 4 / r["wall_s"]) < 1e-9
@@ -93,9 +93,10 @@ def test_measured_wavefront_two_lanes():
     r = _wavefront(2, [])
     assert r["n_gpus"] == 2 and r["chunks"] == 4 and r["lanes"] == 2 and "measured wavefront" in r["config"]["parallelism"]
     assert abs(r["value_shortened_run"] - 21.0 * 4 / r["wall_s"]) < 1e-9 and r["value_modelled"] > 0
-    # 3 steps: scaled per stage (2 K + 2 forwards; 2 K in the stage without a refresh pair; 2 in the first stage of chunks >= 2), which
-    # is LESS than one 102 / 8 for everything (that over-stated `value` by ~10 % at K = 2)
-    assert abs(r["wall_scale_to_50_steps"] - _scale_to_50(3, 4)) < 1e-9 and r["wall_scale_to_50_steps"] < 102.0 / 8.0
+    # 3 steps: scaled per stage (2 K + 2 forwards; 2 K in the stage without a refresh pair, the heaviest one: 100 / 6 there; a constant 2
+    # in the first stage of chunks >= 2) -- MORE than one 102 / 8 for everything here (that factor over-stated `value` by ~10 %
+    # at K = 2)
+    assert abs(r["wall_scale_to_50_steps"] - _scale_to_50(3, 4)) < 1e-9 and 102.0 / 8.0 < r["wall_scale_to_50_steps"] < 100.0 / 6.0
     assert abs(r["value"] - r["value_shortened_run"] / r["wall_scale_to_50_steps"]) < 1e-9
     assert len(r["chunk_s"]) == 4 and len(r["stagger_s"]) == 3 and all(s > 0 for s in r["stagger_s"])
     # chunk c + 1 cannot start before chunk c's anchor stage is done (the dependency is real)
