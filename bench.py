@@ -683,7 +683,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     step_s = [e0.elapsed_time(e1) * 1e-3 for e0, e1 in ev]
-    attn_blocks, attn_redone, attn_waves_bad, attn_predicted = eng.read_attn_stats() if attn_stats is not None else (None, None, None, None)   # of the timed region (graph replays included)
+    attn_blocks, attn_redone, attn_waves_bad, attn_predicted, attn_remembered = eng.read_attn_stats() if attn_stats is not None else (None,) * 5   # of the timed region (graph replays included)
     # ---- eager pass (after the timed region when that one replayed graphs): one rotation of the four stages with a hipEvent
     # pair around every self-attention launch (all kernel classes with --profile-all) -> `eager` figures and `roofline`
     eager_step_s = None
@@ -804,11 +804,14 @@ def main():
                 "attn_blocks_redone_fraction": (attn_redone / attn_blocks) if attn_blocks else None,
                 # per WAVE (64 of a block's 256 query rows): how many held a failing row themselves -- what a finer redo unit would pay for
                 "attn_waves_failed_fraction": (attn_waves_bad / (4.0 * attn_blocks)) if attn_blocks else None,
-                # blocks their history byte (the previous step's failure) sent straight to the GENERAL pass: 1.66 FAST-pass times instead of 2.66
+                # blocks their history (an earlier failure even on remembered references) sent straight to the GENERAL pass: 1.66 FAST-pass
+                # times instead of 2.66 -- and blocks whose FAST pass HELD on the lane references their history remembered: 1.0
                 "attn_blocks_predicted": attn_predicted,
-                "attn_blocks_predicted_fraction": (attn_predicted / attn_blocks) if attn_blocks else None} if attn_stats is not None else {}),
+                "attn_blocks_predicted_fraction": (attn_predicted / attn_blocks) if attn_blocks else None,
+                "attn_blocks_fast_on_remembered_reference": attn_remembered,
+                "attn_blocks_fast_on_remembered_reference_fraction": (attn_remembered / attn_blocks) if attn_blocks else None} if attn_stats is not None else {}),
             "attn_history": "off (--no-attn-history): stateless self-attention" if args.no_attn_history else
-                            "on: one byte per (stage, branch, layer, head, 256-row query block) carried from step to step (include/mmpl_hip.h)",
+                            "on: a state byte + 128 lane references per (stage, branch, layer, head, 256-row query block) carried from step to step (include/mmpl_hip.h)",
             **({"weights": f"heavy-tailed synthetic (QK-norm gains x{args.heavy_tail_gain:g}" +
                            (f" on {args.heavy_tail_heads:g} of every layer's heads" if args.heavy_tail_heads is not None else "") +
                            ", six massive-activation channels): NOT the headline workload"}

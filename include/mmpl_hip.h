@@ -66,11 +66,11 @@ int mmpl_dit_set_image_kv(MmplDit* h, const void* img_k, const void* img_v, int 
 
 /* Optional diagnostics of the self-attention kernel's data dependence.  attn_w64_kernel runs a max-free FAST softmax pass per
  * 256-row query block and redoes the block with the GENERAL (running-reference) pass if any row sum left [2^-100, 2^100].
- * stats_dev: 4 x uint64 in device memory (borrowed; zero them yourself), incremented by every self-attention launch of
+ * stats_dev: 5 x uint64 in device memory (borrowed; zero them yourself), incremented by every self-attention launch of
  * mmpl_dit_forward on this handle, inside hipGraph replays too: [0] += blocks run, [1] += blocks whose FAST pass failed and that were
  * redone (both passes paid), [2] += waves (64 of a block's 256 query rows) that held a failing row themselves -- the unit a
- * finer-grained redo would pay for, [3] += blocks their history byte sent straight to the GENERAL pass (`attn_history`).  NULL
- * switches it off. */
+ * finer-grained redo would pay for, [3] += blocks their history sent straight to the GENERAL pass, [4] += blocks whose FAST pass held
+ * on the references their history remembered (`attn_history`).  NULL switches it off. */
 int mmpl_dit_set_attn_stats(MmplDit* h, void* stats_dev);
 
 /* CausalFPSWanModel._forward_inference (causal_fps_model.py:708-837) behind WanFPSWrapper.forward
@@ -100,15 +100,18 @@ int mmpl_dit_set_attn_stats(MmplDit* h, void* stats_dev);
  *                fingerprint the layer-0 K / V slots they attend to on the device (one pass over them), the share_in forward
  *                compares; outside a stream capture it then fails with an error on a mismatch, inside one the mismatch is counted
  *                on the device (mmpl_dit_share_check_failures).
- *   attn_history (may be NULL): dev, mmpl_dit_attn_history_bytes(h, n_frames) bytes owned by the caller, one byte per (layer, head,
- *                256-row query block, split part) of the self-attention: the OUTCOME of this attention's previous launch.  Hand the
- *                same buffer to every forward of one (CFG branch, stage) -- consecutive denoise steps see the same K / V and nearly
- *                the same q -- and zero it when the stage changes.  A query block whose max-free FAST softmax pass failed on the
- *                previous launch (heavy-tailed scores) then starts in the GENERAL pass instead of paying for both (FAST is retried
- *                after 8, then 16, then 31 launches so that the byte can clear).  Both passes are the exact softmax up to rounding,
- *                so any contents give a correct result -- but WHICH pass runs decides the rounding: with a history the output bits
- *                depend on the launches before (two identical sequences of launches from a zeroed history are bit-identical, eager or
- *                replayed from a hipGraph); NULL = stateless, every launch bit-reproducible by itself. */
+ *   attn_history (may be NULL): dev, mmpl_dit_attn_history_bytes(h, n_frames) bytes owned by the caller: per (layer, head, 256-row query
+ *                block, split part) of the self-attention one state byte and 128 int16 lane references -- what this attention's
+ *                previous launch learned.  Hand the same buffer to every forward of one (CFG branch, stage) -- consecutive denoise
+ *                steps see the same K / V and nearly the same q -- and zero it when the stage changes.  A query block whose max-free
+ *                FAST softmax pass failed (heavy-tailed scores) then stops paying for both passes: from its first failure on every pass
+ *                leaves each lane's mean log-sum-exp, the next FAST pass takes that as its reference and holds wherever the scores'
+ *                range is; a block that fails even so goes straight to the GENERAL pass for 7, then 15, then 30 launches between
+ *                retries.  Both passes are the exact softmax up to rounding, so any contents give a correct result -- but which pass
+ *                runs, against which reference, decides the rounding: with a history the output bits depend on the launches before
+ *                (two identical sequences of launches from a zeroed history are bit-identical, eager or replayed from a hipGraph; a
+ *                block that never fails never leaves the zero state and computes the stateless kernel's bits); NULL = stateless, every
+ *                launch bit-reproducible by itself. */
 int mmpl_dit_forward(MmplDit* h, const void* x_in, const float* t_dev, int n_frames, const int* frame_ids,
                      const int* write_slots, const int* visible_slots, int n_visible, void* k_cache, void* v_cache,
                      int n_slots, const void* cross_k, const void* cross_v, int cross_rows, void* share_out, const void* share_in,
@@ -148,7 +151,7 @@ int mmpl_attn_fwd_variant(const void* q, int ldq, void* o, int ldo, const void* 
 /* The DiT forward's self-attention launch by itself (variant 4 above: attn_w64_kernel on a q its producer multiplied by
  * softmax_scale * log2(e) before rounding it to bf16), with the two optional pieces of state mmpl_dit_forward threads through it:
  * history = mmpl_attn_history_bytes(Lq, num_heads) device bytes (see mmpl_dit_forward's attn_history; NULL = stateless) and
- * stats_dev = 4 x uint64 (see mmpl_dit_set_attn_stats; NULL = off). */
+ * stats_dev = 5 x uint64 (see mmpl_dit_set_attn_stats; NULL = off). */
 size_t mmpl_attn_history_bytes(int Lq, int num_heads);
 int mmpl_attn_fwd_history(const void* q, int ldq, void* o, int ldo, const void* const* k_pages, const void* const* v_pages,
                           int ldk, int ldv, int n_pages, int page_rows, int Lq, int num_heads, float softmax_scale,

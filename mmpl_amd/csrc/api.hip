@@ -560,7 +560,7 @@ int mmpl_dit_share_check_failures(MmplDit* h, long long* count, mmpl_stream_t st
 size_t mmpl_dit_attn_history_bytes(const MmplDit* h, int n_frames) {
   return h ? (size_t)h->cfg.num_layers * mmpl_attn_history_bytes(n_frames * h->S, h->cfg.num_heads) : 0;
 }
-size_t mmpl_attn_history_bytes(int Lq, int num_heads) { return (size_t)num_heads * ((Lq + 255) / 256) * 4; }
+size_t mmpl_attn_history_bytes(int Lq, int num_heads) { return mmpl_attention_history_bytes(Lq, num_heads); }
 
 int mmpl_attn_fwd_history(const void* q, int ldq, void* o, int ldo, const void* const* k_pages, const void* const* v_pages,
                           int ldk, int ldv, int n_pages, int page_rows, int Lq, int num_heads, float softmax_scale,

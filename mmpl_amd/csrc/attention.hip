@@ -517,6 +517,7 @@ hipError_t mmpl_launch_attention(const AttnArgs& a_in, hipStream_t s) {
     else hipLaunchKernelGGL(attn_fwd_kernel<0>, dim3(n_qb * a.H), dim3(512), SMEM, s, a);
     return hipGetLastError();
   }
+  if (a.history) a.history_mem = reinterpret_cast<short*>(a.history + mmpl_attention_history_state_bytes(a.Lq, a.H));
   if (hipError_t e = mmpl_dyn_smem_once(mmpl_attention_w64_symbol(0), mmpl_attention_w64_smem()); e != hipSuccess) return e;
   if (hipError_t e = mmpl_dyn_smem_once(mmpl_attention_w64_symbol(1), mmpl_attention_w64_smem()); e != hipSuccess) return e;
   auto run = [&](int blocks, int local_base, int sp, bool split) { mmpl_launch_attention_w64(a, blocks, local_base, sp, split, s); };

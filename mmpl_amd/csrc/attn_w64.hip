@@ -96,6 +96,8 @@ struct Ctx {
   uint32_t kslot, vslot;                       // LDS address of this wave's piece 0 in the slot the cursor tile goes to
   uint32_t rk, rv;                             // ring offsets of the tiles the next B phase reads (K(j+1), V(j))
   int first[2];                                // GENERAL pass: stream has not finished its first tile yet
+  int use_mem;                                 // FAST pass: take m_ref from mem_ref (the block's history) instead of sampling the first tiles
+  float mem_ref;                               // ... this lane's remembered reference (log2 units; an integer value)
   int prow, drow, dchunk;
   uint32_t wave_slot;                          // this wave's first piece within a ring slot
 
@@ -373,6 +375,13 @@ template <int MODE> MMPL_DEV void w64_pass(Ctx& k) {
 
   k.plan(0);
   if constexpr (MODE == 0 && !ABL(~0)) {
+    float ref;
+    if (k.use_mem) {
+      // FAST pass reference from the block's history: the mean log-sum-exp of this lane's two query rows on the previous launch of
+      // this attention (kernel epilogue below) -- consecutive denoise steps see the same K / V and nearly the same q, so the row sums
+      // come out near 2^0, in the middle of the window, wherever the scores' range is (no sampling: the pipeline starts at once)
+      ref = k.mem_ref;
+    } else {
     // FAST pass reference (header): the scores of KV tile 0 for both query blocks, their largest per lane (= two query rows) + offset
     // becomes m_ref; it enters every later score through the C operand of the tile's first MFMA, so the pipeline below is untouched.
     sfor<16>([&k](auto gi) { k.template mfma_qk<0, decltype(gi)::value>(); });
@@ -400,8 +409,10 @@ template <int MODE> MMPL_DEV void w64_pass(Ctx& k) {
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     mx = fminf(fmaxf(mx, -1e30f), 1e30f);              // (a NaN / inf score: the end-of-pass check fails and GENERAL takes over)
-    k.mref[0] = k.mref[1] = mx + FAST_REF_OFFSET;
-    k.mbase = -(mx + FAST_REF_OFFSET);
+    ref = mx + FAST_REF_OFFSET;
+    }
+    k.mref[0] = k.mref[1] = ref;
+    k.mbase = -ref;
     k.masked = 1;                                      // make plan() rewrite the C-operand tile (mask of tile 0 included) on the new base
     k.plan(0);
   }
@@ -501,19 +512,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 
   // ---- the FAST pass; if any row of the block cannot be held by it (see the header), the GENERAL pass from scratch.
-  // With a history byte (AttnArgs.history: one per (head, query block, split part), owned by the caller, carried from one launch of
-  // the same (layer, CFG branch, stage) to the next) a block whose FAST pass failed LAST time does not pay for it again: consecutive
-  // denoise steps see the same K / V and nearly the same q, so it goes straight to GENERAL (1.66 instead of 2.66 FAST-pass times).
-  // Byte: 0 = try FAST; else (level << 5 | countdown): countdown > 1 -> GENERAL, countdown - 1; countdown == 1 -> FAST is tried again
-  // (so the flag can clear) and a failure re-arms it with a longer interval: 8, 16, then 31 launches.  Either pass is the exact
-  // softmax up to rounding, so any byte value gives a correct result; WHICH pass ran decides the rounding, i.e. with a history the
-  // bits depend on the launches before (identical sequences of launches give identical bits).
+  // With a history (AttnArgs.history / history_mem: per (head, query block, split part) one state byte and one int16 per lane pair,
+  // owned by the caller, carried from one launch of the same (layer, CFG branch, stage) to the next -- consecutive denoise steps see the
+  // same K / V and nearly the same q) a block whose FAST pass failed does not keep paying for both passes:
+  //   * from the first failure on every pass leaves, per lane, the mean log-sum-exp of its two query rows (log2 units, rounded to an
+  //     integer), and the next FAST pass takes THAT as its reference instead of sampling the first four KV tiles: the row sums then
+  //     come out near 2^0 whatever the range of the scores (1.0 instead of 2.66 FAST-pass times);
+  //   * a block whose FAST pass fails even so (two rows of a lane further apart than the window is wide) goes straight to GENERAL on the
+  //     following launches (1.66): FAST is tried again on the 8th, after another failure on the 16th, then every 31st launch.
+  // State byte: bit 7 = the lane references are valid; bits 5-6 = back-off level; bits 0-4 = countdown (> 1: GENERAL, decrement;
+  // 1: FAST is tried again; 0: FAST).  0 = no history: the stateless kernel, bit for bit (blocks that never fail never leave 0).
+  // Either pass is the exact softmax up to rounding, so any contents give a correct result; WHICH pass ran, and against which reference,
+  // decides the rounding: with a history the bits depend on the launches before (identical sequences of launches give identical bits).
   extern __shared__ __attribute__((aligned(16))) char w64_smem[];
   volatile int* redo = reinterpret_cast<volatile int*>(w64_smem + 2 * RING * TILE);
-  unsigned char* hist = a.history ? a.history + ((((size_t)head * n_qb + qb) << 2) | (SPLIT ? part : 0)) : nullptr;
+  const size_t hidx = (((size_t)head * n_qb + qb) << 2) | (SPLIT ? part : 0);
+  unsigned char* hist = a.history ? a.history + hidx : nullptr;
+  short* hmem = a.history ? a.history_mem + hidx * 128 + wave * 32 + l31 : nullptr;
   int hstate = 0;
   if (hist) hstate = __builtin_amdgcn_readfirstlane((int)*reinterpret_cast<volatile unsigned char*>(hist));
   const bool try_fast = (hstate & 31) <= 1;
+  const bool have_mem = (hstate & 128) != 0;
+  k.use_mem = have_mem;
+  k.mem_ref = 0.f;
+  if (have_mem && try_fast) k.mem_ref = (float)*reinterpret_cast<volatile short*>(hmem);
   int redo_block = 1;
   bool bad = false;
   if (try_fast) {
@@ -534,23 +556,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (a.redo_stats) {
     if (tid == 0) {
       atomicAdd(a.redo_stats, 1ull);
-      if (!try_fast) atomicAdd(a.redo_stats + 3, 1ull);                    // predicted: straight to GENERAL
+      if (!try_fast) atomicAdd(a.redo_stats + 3, 1ull);                    // straight to GENERAL
       else if (redo_block) atomicAdd(a.redo_stats + 1, 1ull);              // paid for both passes
+      else if (have_mem) atomicAdd(a.redo_stats + 4, 1ull);                // FAST held on the remembered references
     }
     if (__any(bad) && lane == 0) atomicAdd(a.redo_stats + 2, 1ull);        // waves (64 query rows) that held a failing row themselves
   }
   if (redo_block) w64_pass<1>(k);
-  // The byte is rewritten only HERE: every wave of the block has passed a barrier since it read it (the vote's, or the GENERAL pass's
-  // own), so no late wave can see the new value and take the other branch (a countdown going 2 -> 1 flips the decision).
-  if (hist && tid == 0) {
+  // The history is rewritten only HERE: every wave of the block has passed a barrier since it read the state byte (the vote's, or the
+  // GENERAL pass's own), so no late wave can see the new value and take the other branch (a countdown going 2 -> 1 flips the decision).
+  if (hist) {
     int ns;
-    if (!try_fast) ns = hstate - 1;
-    else if (!redo_block) ns = 0;
+    if (!try_fast) ns = hstate - 1;                                        // (keeps bit 7 and the level)
+    else if (!redo_block) ns = hstate & 128;
+    else if (!have_mem) ns = 128;                                          // first failure: the references below, FAST again next time
     else {
-      const int level = hstate ? min((hstate >> 5) + 1, 2) : 0;
-      ns = (level << 5) | min(8 << level, 31);
+      const int level = (hstate & 31) ? min(((hstate >> 5) & 3) + 1, 2) : 0;
+      ns = 128 | (level << 5) | min(8 << level, 31);
     }
-    *hist = (unsigned char)ns;
+    if (ns & 128) {
+      // mean log-sum-exp of the lane's two query rows relative to nothing: m_ref + log2(l) (both passes keep l relative to m_ref)
+      float lse = 0.f;
+#pragma unroll
+      for (int X = 0; X < 2; ++X) {
+        const float l_tot = k.l[X] + __shfl_xor(k.l[X], 32, 64);
+        lse += 0.5f * (k.mref[X] + __builtin_amdgcn_logf(l_tot));          // v_log_f32 = log2
+      }
+      lse = fminf(fmaxf(lse, -32000.f), 32000.f);                          // (a NaN -- only ever from non-finite scores -- becomes -32000)
+      if (hi == 0) *hmem = (short)__builtin_rintf(lse);
+    }
+    if (tid == 0) *hist = (unsigned char)ns;
   }
 
   // ---- epilogue: lane (q = l31, hi) holds O_X[q][32*nb + 8*g + 4*hi + {0..3}] in a[64 X + 16 nb + 4 g ..+3]

@@ -68,14 +68,15 @@ struct AttnArgs {
   // attn_fwd_kernel with ONE page only: the page's last row stands for `last_row_copies` identical keys (same K row, same V row):
   // its score gets + ln(copies) / scale, i.e. its softmax weight is multiplied by copies.  0 / 1 = a plain row.
   int last_row_copies;
-  // attn_w64_kernel, optional: four device counters {blocks run, blocks whose FAST pass failed and were redone by the GENERAL pass,
-  // WAVES (64 query rows) that held a failing row themselves, blocks sent straight to the GENERAL pass by their history byte}
-  // (how data-dependent is the kernel's time on THIS input? -- bench.py --heavy-tail)
+  // attn_w64_kernel, optional: five device counters {blocks run, blocks whose FAST pass failed and were redone by the GENERAL pass,
+  // WAVES (64 query rows) that held a failing row themselves, blocks their history sent straight to the GENERAL pass, blocks whose
+  // FAST pass held on the references their history remembered} (how data-dependent is the kernel's time on THIS input? -- bench.py --heavy-tail)
   unsigned long long* redo_stats;
-  // attn_w64_kernel, optional: one byte per (head, 256-row query block, split part): [H * ceil(Lq / 256) * 4], carried by the caller
-  // from one launch to the next launch of the same attention (same layer, CFG branch and stage shape); zero = no history.  A block
-  // whose FAST pass failed last time starts in the GENERAL pass (attn_w64.hip).  nullptr: every block tries FAST (stateless).
+  // attn_w64_kernel, optional: mmpl_attn_history_bytes(Lq, H) bytes carried by the caller from one launch to the next launch of the same
+  // attention (same layer, CFG branch and stage shape); all zero = no history.  [H * ceil(Lq / 256) * 4] state bytes (head, query block,
+  // split part), padded to 256 B, then per state byte 128 int16 lane references (attn_w64.hip).  nullptr: stateless.
   unsigned char* history;
+  short* history_mem;              // set by mmpl_launch_attention: history + the padded state bytes
 };
 // Work item `local` of XCD `xcd` -> (head, query block) for attn_w64_kernel / attn_merge_kernel (the hardware deals workgroups
 // round-robin to the 8 XCDs: blockIdx & 7).  H % 8 == 0: XCD x owns heads x, x+8, ...; any other head count (Wan 1.3B: 12):
@@ -104,6 +105,8 @@ int mmpl_attention_w64_smem();
 const void* mmpl_attention_w64_symbol(int split);
 void mmpl_launch_attention_w64(const AttnArgs& a, int blocks, int local_base, int sp, bool split, hipStream_t s);
 size_t mmpl_attention_split_ws_bytes();     // upper bound of what a launch can use
+inline size_t mmpl_attention_history_state_bytes(int Lq, int H) { return ((size_t)H * ((Lq + 255) / 256) * 4 + 255) & ~(size_t)255; }
+inline size_t mmpl_attention_history_bytes(int Lq, int H) { return mmpl_attention_history_state_bytes(Lq, H) + (size_t)H * ((Lq + 255) / 256) * 4 * 128 * sizeof(short); }
 hipError_t mmpl_launch_attention(const AttnArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- norms / rope / elementwise (elementwise.hip)

@@ -124,14 +124,15 @@ class DitEngine:
 
     # ------------------------------------------------------------------ diagnostics
     def enable_attn_stats(self) -> torch.Tensor:
-        """Count the self-attention kernel's query blocks and what its data-dependent softmax passes did with them: int64 [4] on the
+        """Count the self-attention kernel's query blocks and what its data-dependent softmax passes did with them: int64 [5] on the
         device = {blocks, blocks whose max-free FAST pass failed and that the GENERAL pass redid (both paid), waves (64 rows) that
-        held a failing row, blocks their history byte sent straight to the GENERAL pass}, incremented by every later forward.
+        held a failing row, blocks their history sent straight to the GENERAL pass, blocks whose FAST pass held on the references
+        their history remembered}, incremented by every later forward.
         The counter's address is a kernel argument: a hipGraph captured while stats are on keeps counting on every replay
         whatever `disable_attn_stats` says later, and one captured while they are off never counts.  One atomic per 256-row
         block; `bench.py` switches it on for its diagnostic modes only."""
         if self._attn_stats is None:
-            self._attn_stats = torch.zeros(4, dtype=torch.int64, device=self.device)
+            self._attn_stats = torch.zeros(5, dtype=torch.int64, device=self.device)
         _lib.check(self._lib.mmpl_dit_set_attn_stats(self._h, _lib.ptr(self._attn_stats)), "mmpl_dit_set_attn_stats")
         return self._attn_stats
 
@@ -139,19 +140,21 @@ class DitEngine:
         """Later eager forwards and later captures stop counting (graphs captured before keep their setting)."""
         _lib.check(self._lib.mmpl_dit_set_attn_stats(self._h, None), "mmpl_dit_set_attn_stats")
 
-    def read_attn_stats(self, reset: bool = False) -> Tuple[int, int, int, int]:
-        """(blocks run, blocks redone, waves that held a failing row, blocks predicted) since the counters were last zeroed."""
+    def read_attn_stats(self, reset: bool = False) -> Tuple[int, int, int, int, int]:
+        """(blocks run, blocks redone, waves that held a failing row, blocks sent straight to GENERAL, blocks whose FAST pass held on
+        remembered references) since the counters were last zeroed."""
         if self._attn_stats is None:
             raise RuntimeError("DitEngine.read_attn_stats: enable_attn_stats() was never called on this engine")
-        blocks, redone, waves, predicted = (int(v) for v in self._attn_stats.cpu())
+        vals = tuple(int(v) for v in self._attn_stats.cpu())
         if reset:
             self._attn_stats.zero_()
-        return blocks, redone, waves, predicted
+        return vals
 
     def new_attn_history(self, n_frames: Optional[int] = None) -> torch.Tensor:
-        """Zeroed history of the self-attention's softmax passes for `forward(attn_history=...)`: one byte per (layer, head, 256-row
-        query block, split part), sized for stages of up to `n_frames` frames (default: the engine's largest).  One buffer per (CFG
-        branch, stage); `zero_()` it when the stage changes (include/mmpl_hip.h)."""
+        """Zeroed history of the self-attention's softmax passes for `forward(attn_history=...)`: a state byte and 128 int16 lane
+        references per (layer, head, 256-row query block, split part), sized for stages of up to `n_frames` frames (default: the
+        engine's largest; ~160 MB for Wan 14B at 720p).  One buffer per (CFG branch, stage); `zero_()` it when the stage changes
+        (include/mmpl_hip.h)."""
         n = self._lib.mmpl_dit_attn_history_bytes(self._h, self.max_frames if n_frames is None else n_frames)
         return torch.zeros(n, dtype=torch.uint8, device=self.device)
 

@@ -44,7 +44,7 @@ def test_t5_and_vae_argument_errors():
     assert "weights not bound" in _err(lib.mmpl_dit_forward(None, None, None, 1, None, None, None, 0, None, None, 15, None, None, 512, None, None, None, None, None, 0, None))
     assert "shape must be 32 or 16" in _err(lib.mmpl_probe_mfma_tflops(8, 1.0, None))
     assert "null argument" in _err(lib.mmpl_dit_share_check_failures(None, None, None))
-    assert lib.mmpl_dit_attn_history_bytes(None, 3) == 0 and lib.mmpl_attn_history_bytes(256 * 3 + 1, 12) == 12 * 4 * 4
+    assert lib.mmpl_dit_attn_history_bytes(None, 3) == 0 and lib.mmpl_attn_history_bytes(256 * 3 + 1, 12) == 256 + 12 * 4 * 4 * 128 * 2
 
 
 def test_kernel_entry_points_reject_bad_shapes():

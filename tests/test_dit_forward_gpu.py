@@ -302,8 +302,8 @@ def test_attention_redo_counters_blocks_and_waves():
         kc, vc = eng.new_kv_cache(15)
         y = eng.forward(x, t, frames, [0, 1], [0, 1], kc, vc, kv[0], kv[1], cross_rows=kv.rows)
         torch.cuda.synchronize()
-        blocks, redone, waves, predicted = eng.read_attn_stats(reset=True)
-        assert eng.read_attn_stats() == (0, 0, 0, 0) and predicted == 0       # (no history was handed in: nothing is predicted)
+        blocks, redone, waves, predicted, remembered = eng.read_attn_stats(reset=True)
+        assert eng.read_attn_stats() == (0, 0, 0, 0, 0) and predicted == 0 and remembered == 0    # (no history was handed in)
         assert torch.isfinite(y.float()).all()
         n_qb = -(-2 * eng.S // 256)
         items = cfg["num_layers"] * cfg["num_heads"] * n_qb                # (a split-KV tail round runs a query block as 2-4 blocks)
@@ -313,7 +313,7 @@ def test_attention_redo_counters_blocks_and_waves():
         eng.disable_attn_stats()
         eng.forward(x, t, frames, [0, 1], [0, 1], kc, vc, kv[0], kv[1], cross_rows=kv.rows)
         torch.cuda.synchronize()
-        assert eng.read_attn_stats() == (0, 0, 0, 0)                  # off: later eager forwards do not count
+        assert eng.read_attn_stats() == (0, 0, 0, 0, 0)               # off: later eager forwards do not count
     print("attention redo counters {gain: (blocks, blocks redone, waves with a failing row)}:", seen)
     assert seen[1.0][1] == 0 and seen[12.0][1] > 0
 

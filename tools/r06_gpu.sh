@@ -14,7 +14,7 @@ import json,sys
 r=json.loads(open('$1').read().strip().splitlines()[-1]); rf=r.get('roofline',{})
 print('$2', 'step', round(r['sec_per_denoise_step'],4), [round(x,4) for x in r['sec_per_denoise_step_by_stage']], 'attn', round(rf.get('achieved',0),1), 'frac', round(rf.get('frac',0),4),
       'of_sustained', round(rf.get('frac_of_sustained',0),4), 'probe', {k[-12:]:round(v) for k,v in (rf.get('sustained_probe_tflops') or {}).items()}, 'gemm', r.get('gemm_tflops'),
-      'redo', r.get('attn_blocks_redone_fraction'), 'predicted', r.get('attn_blocks_predicted_fraction'), 'shares', r.get('kernel_time_share'))"
+      'redo', r.get('attn_blocks_redone_fraction'), 'predicted', r.get('attn_blocks_predicted_fraction'), 'remembered', r.get('attn_blocks_fast_on_remembered_reference_fraction'), 'shares', r.get('kernel_time_share'))"
 }
 for spec in "$@"; do
   step=${spec%%:*}; arg=${spec#*:}; [ "$arg" = "$spec" ] && arg=""
