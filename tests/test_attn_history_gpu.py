@@ -30,9 +30,11 @@ def _sp():
 
 def _spiked_case(split_tail: bool, heavy_heads=()):
     """q / K / V with a few keys that are large multiples of a few queries (scores no FAST pass can hold) in known query blocks;
-    heavy_heads: instead, those heads' K rows scaled x 7 in the first page and x 70 in the later ones: every query row's scores have a
-    standard deviation of ~10 (log2 units) over the keys the FAST pass samples its reference from and ~100 over the rest, so the row
-    maxima (~330) lie far above anything the sample predicts -- every row of the head is heavy-tailed, like a large QK-norm gain."""
+    heavy_heads: instead, those heads' K rows scaled x 4 in the first page and x 45 in the later ones: every query row's scores have a
+    standard deviation of ~6 (log2 units) over the keys the FAST pass samples its reference from and ~65 over the rest, so the row
+    log-sum-exps (~210 +- 27) lie far above anything the sample predicts -- every block of the head fails the sampled reference, like
+    under a large QK-norm gain -- while two rows of a lane stay well within the window of each other (their spread is what a shared
+    reference cannot absorb: at +-41, a scale of 70, one block in ten fails on the remembered reference too)."""
     torch.manual_seed(12)
     dev = "cuda:0"
     H, S, n_pages = 8, 640, 3
@@ -46,8 +48,8 @@ def _spiked_case(split_tail: bool, heavy_heads=()):
     hot_heads = (0, 3, 7)
     if heavy_heads:
         for h in heavy_heads:
-            kc32[:S, h * 128:(h + 1) * 128] *= 7.0
-            kc32[S:, h * 128:(h + 1) * 128] *= 70.0
+            kc32[:S, h * 128:(h + 1) * 128] *= 4.0
+            kc32[S:, h * 128:(h + 1) * 128] *= 45.0
         hot_heads = tuple(heavy_heads)
     else:
         for r, kk in zip(hot_rows, hot_keys):
@@ -221,7 +223,9 @@ def test_identical_sequences_are_bit_identical_eager_and_graph():
         outs_e.append(eng.forward(x, t, frames, slots, vis, kc, vc, kv[0], kv[1], cross_rows=kv.rows, attn_history=hist).clone())
         per_step.append(eng.read_attn_stats())
     assert per_step[0][1] > 0 and per_step[0][3] == 0 and per_step[0][4] == 0, per_step     # step 1: FAST failed somewhere, paid twice
-    assert per_step[1][3] + per_step[1][4] + per_step[1][1] >= per_step[0][1] and per_step[1][4] > 0, per_step      # step 2: the history is in play
+    # ... and by step 3 the history decides: blocks run FAST on remembered references or (these wild synthetic scores: a noise cache x 4
+    # under gains x 8) fail on them too and go straight to GENERAL
+    assert per_step[2][3] + per_step[2][4] > 0 and per_step[2][1] < per_step[0][1], per_step
     kc_e, vc_e = kc.clone(), vc.clone()
 
     kc, vc = caches()
