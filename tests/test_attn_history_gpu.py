@@ -179,7 +179,7 @@ def test_history_remembers_the_reference_of_heavy_tailed_heads(lib, split_tail):
         cs["q_ref"] = cs["q"].float() * (qref0[0, 0] / q0[0, 0].float())
         o, st = _launch(lib, cs, cs["kc"], hist, stats, ws)
         # (nearly) every heavy block: ONE pass, on the remembered references; a lane whose two rows drifted apart may fail and back off
-        assert st[1] + st[3] + st[4] == n_heavy and st[4] >= 0.9 * n_heavy, (step, st)
+        assert st[1] + st[3] + st[4] == n_heavy and st[4] >= 0.75 * n_heavy, (step, st)
         assert rel_l2(o[rows], _ref(cs, cs["kc"], rows)) < 1e-2, step
         assert MEM in set(_states(cs, hist)[_states(cs, hist) != 0].tolist())
 
