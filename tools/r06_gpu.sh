@@ -62,6 +62,10 @@ for spec in "$@"; do
         python bench.py --model 1.3B --res 480p --steps 16 --warmup 8 --no-cpu-baseline --no-vae $arg > $out/is_tmp.json 2>> $out/bench.err; line $out/is_tmp.json "1.3B/480p [lib=$v]" >> $out/insitu_ab.log
       done
       cp tools/build/libmmpl_hip_new.so mmpl_amd/lib/libmmpl_hip.so; cat $out/insitu_ab.log ;;
+    attnhash)    # do two PREBUILT libraries compute the same self-attention bits (stateless launches)?
+      for v in prev new; do cp tools/build/libmmpl_hip_$v.so mmpl_amd/lib/libmmpl_hip.so; timeout 300 python tools/attn_hash.py 2>&1 | grep "^attnhash" > $out/attnhash_$v.txt; done
+      cp tools/build/libmmpl_hip_new.so mmpl_amd/lib/libmmpl_hip.so
+      diff $out/attnhash_prev.txt $out/attnhash_new.txt > $out/attnhash.diff && echo "identical hashes on every shape" || cat $out/attnhash.diff; cat $out/attnhash_new.txt ;;
     gemmab)      # the four 14B / 720p block GEMMs standalone, two PREBUILT libraries alternating, output hashes
       for v in prev new prev new; do
         cp tools/build/libmmpl_hip_$v.so mmpl_amd/lib/libmmpl_hip.so
