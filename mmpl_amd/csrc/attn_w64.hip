@@ -254,7 +254,15 @@ struct Ctx {
     vslot = RING * TILE + ((vslot + TILE) & (RING * TILE - 1));
     vsoff += vstep;
   }
-  MMPL_DEV void mfma_write_pad() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
+  // Wait states between the score MFMAs (hand-issued: the compiler's hazard recogniser does not see them) and compiler-generated VALU
+  // reads of S.  The S tiles are in-out operands of the pad: a read of S is then data-dependent on it and cannot be scheduled above it.
+  // (Without that tie the `v_max` chain of score_max() was free to move in front of the nops -- it did, differently from build to
+  // build: the sampled reference then came from accumulators still in flight.  Harmless for the result -- any reference inside the
+  // window gives the exact softmax -- but it made the stateless kernel's BITS depend on the compiler's schedule: round 6, found by
+  // hashing the outputs of two builds, profiles/r06z_attn_hash_r05_vs_r06.log.)
+  MMPL_DEV void mfma_write_pad() {
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[1][0]), "+v"(S[1][1])::"memory");
+  }
   MMPL_DEV void rotate() {                               // end of B(j): the next B phase reads the next ring slots
     rk = (rk + TILE) & (RING * TILE - 1);
     rv = (rv + TILE) & (RING * TILE - 1);
@@ -289,6 +297,9 @@ struct Ctx {
   }
   // GENERAL pass, slow path of one tile of stream X (see the header): returns the tile's partial row sum.
   template <int X> MMPL_DEV float slow(float lt) {
+    // (the reads of S below must stay behind every statement of the schedule that precedes this call -- the MFMAs issued since S_X was
+    // finished ARE its wait states: an empty statement that "modifies" S pins them there)
+    asm volatile("" : "+v"(S[X][0]), "+v"(S[X][1]));
     float mx = S[X][0][0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[X][0][r]);
