@@ -17,14 +17,14 @@ LAT = (16, 24)
 TRAJ_TOL = 1.5e-2
 
 
-def _setup(mode="t2v", steps=2, with_vae=False, lat=LAT, cfg_name="tiny", weight_seed=2, ctx_seeds=(21, 22), n_valid=(40, 12)):
+def _setup(mode="t2v", steps=2, with_vae=False, lat=LAT, cfg_name="tiny", weight_seed=2, ctx_seeds=(21, 22), n_valid=(40, 12), weights_on="cpu"):
     from mmpl_amd.geometry import Geometry
     from mmpl_amd.pipeline import CausalFPSInferencePipeline
     from mmpl_amd.synthetic import WAN_CONFIGS, dit_state_dict, philox_normal, vae_state_dict
     from mmpl_amd.wan_wrapper import WanFPSWrapper, WanTextEncoder, WanVAEWrapper
     cfg = WAN_CONFIGS[cfg_name]
     geo = Geometry(*lat)
-    sd = dit_state_dict(cfg, seed=weight_seed)
+    sd = dit_state_dict(cfg, seed=weight_seed, device=weights_on)      # ("cuda:0": 14B-sized weights are drawn on the device)
     gen = WanFPSWrapper(is_causal=True, timestep_shift=5.0, model_config=cfg, geometry=geo, device="cuda:0")
     gen.load_state_dict({"model." + k: v for k, v in sd.items()})          # MMPL checkpoint key style
     ctx = {}

@@ -224,23 +224,22 @@ def test_t2v_chunk_50_steps_deeper_model_vs_reference_fixture():
     assert e <= 2 * nf["order_out"] and eh <= 2 * nf["order_handoff"]
 
 
-def test_t2v_chunk_full_size_1p3B_480p_vs_reference_algorithm_on_the_device():
-    """BASELINE configs[1] end to end: Wan2.1-T2V-1.3B (all 30 layers, dim 1536, 12 heads), 480p (60x104), a whole first chunk at 10 UniPC
-    steps per stage = 4 x (10 x 2 + 2) = 88 forwards with CFG 5, step hipGraphs on -- the HIP pipeline against the reference's stage loop
-    (casual_fps_inference.py:250-403, fm_solvers_unipc.py:655-739) as restated by the oracle and executed by PyTorch ON THE DEVICE
-    (tools/traj_executor_floor.py at full size).  Bound = 2 x the device oracle's own K/V-order noise, measured here: the same oracle
-    run with only the frame order of the gathered K / V reversed (the reference's order is `list(set(...))`, i.e. unspecified,
-    causal_fps_model.py:219)."""
-    from mmpl_amd.synthetic import dit_state_dict, philox_normal
+def _full_size_chunk_vs_device_oracle(cfg_name, steps, weight_seed, ctx_seeds, noise_seed, weights_on):
+    """HIP pipeline (step hipGraphs on) vs the oracle's stage loop executed by PyTorch on the device, twice: as is and with only the frame
+    order of the gathered K / V reversed (the reference's order is `list(set(...))`, i.e. unspecified, causal_fps_model.py:219).
+    Returns (HIP-vs-oracle latents, hand-off, oracle order noise latents, hand-off, latents rms, layers)."""
     from oracle import stage_ref
     from oracle import wan_dit_ref as W
     from tests.test_pipeline_gpu import _setup
-    steps, S = 10, (H // 2) * (Wd // 2)
-    pipe, sd, _, cfg, ctx = _setup("t2v", steps=steps, lat=(H, Wd), cfg_name="1.3B", weight_seed=5, ctx_seeds=(51, 52), n_valid=(48, 10))
-    assert cfg["num_layers"] == 30 and cfg["dim"] == 1536 and pipe.sampling_steps == steps
-    noise, renoise = _inputs((H, Wd), 53, 300)
+    S = (H // 2) * (Wd // 2)
+    pipe, sd, _, cfg, ctx = _setup("t2v", steps=steps, lat=(H, Wd), cfg_name=cfg_name, weight_seed=weight_seed, ctx_seeds=ctx_seeds, n_valid=(48, 10),
+                                   weights_on=weights_on)
+    assert pipe.sampling_steps == steps
+    noise, renoise = _inputs((H, Wd), noise_seed, 300)
     lat, hand = _hip_chunk(pipe, noise, renoise)
     del pipe
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()
     dev = "cuda:0"
     sd_d = {k: v.to(dev) for k, v in sd.items()}
@@ -261,10 +260,32 @@ def test_t2v_chunk_full_size_1p3B_480p_vs_reference_algorithm_on_the_device():
         torch.cuda.synchronize()
         outs.append((o.cpu(), h.cpu()))
     (o_out, o_hand), (p_out, p_hand) = outs
-    order, order_h = rel_l2(p_out, o_out), rel_l2(p_hand, o_hand)
-    e, eh = rel_l2(lat, o_out), rel_l2(hand, o_hand)
+    assert torch.isfinite(lat.float()).all()
+    return (rel_l2(lat, o_out), rel_l2(hand, o_hand), rel_l2(p_out, o_out), rel_l2(p_hand, o_hand), o_out.float().pow(2).mean().sqrt().item(),
+            cfg["num_layers"])
+
+
+def test_t2v_chunk_full_size_1p3B_480p_vs_reference_algorithm_on_the_device():
+    """BASELINE configs[1] end to end: Wan2.1-T2V-1.3B (all 30 layers, dim 1536, 12 heads), 480p (60x104), a whole first chunk at 10 UniPC
+    steps per stage = 4 x (10 x 2 + 2) = 88 forwards with CFG 5, step hipGraphs on -- the HIP pipeline against the reference's stage loop
+    (casual_fps_inference.py:250-403, fm_solvers_unipc.py:655-739) as restated by the oracle and executed by PyTorch ON THE DEVICE
+    (tools/traj_executor_floor.py at full size).  Bound = 2 x the device oracle's own K/V-order noise, measured here."""
+    e, eh, order, order_h, rms, layers = _full_size_chunk_vs_device_oracle("1.3B", 10, 5, (51, 52), 53, "cpu")
+    assert layers == 30
     print(f"Wan 1.3B / 480p, all 30 layers, 88 forwards (10 steps x CFG 5 x 4 stages + refresh): HIP vs the reference's algorithm on the device: "
           f"latents {e:.3e} hand-off {eh:.3e}; that executor vs itself with the K/V frame order reversed: {order:.3e} / {order_h:.3e} "
-          f"(bound = 2 x); latents rms {o_out.float().pow(2).mean().sqrt().item():.3f}")
-    assert torch.isfinite(lat.float()).all()
+          f"(bound = 2 x); latents rms {rms:.3f}")
+    assert e <= 2 * order and eh <= 2 * order_h
+
+
+def test_t2v_chunk_full_size_14B_480p_vs_reference_algorithm_on_the_device():
+    """The flagship depth through the whole stage loop: Wan2.1-T2V-14B (all 40 layers, dim 5120, 40 heads) at 480p -- the resolution the
+    reference hard-codes -- a whole first chunk at 4 UniPC steps per stage = 4 x (4 x 2 + 2) = 40 forwards with CFG 5, step hipGraphs,
+    shared block 0 and the attention history on: HIP pipeline vs the reference's algorithm executed by PyTorch on the device, bound = 2 x
+    that executor's own K/V-order noise.  (Synthetic weights drawn on the device; ~150 GB of HBM with both executors' weights and caches.)"""
+    e, eh, order, order_h, rms, layers = _full_size_chunk_vs_device_oracle("14B", 4, 6, (61, 62), 63, "cuda:0")
+    assert layers == 40
+    print(f"Wan 14B / 480p, all 40 layers, 40 forwards (4 steps x CFG 5 x 4 stages + refresh): HIP vs the reference's algorithm on the device: "
+          f"latents {e:.3e} hand-off {eh:.3e}; that executor vs itself with the K/V frame order reversed: {order:.3e} / {order_h:.3e} "
+          f"(bound = 2 x); latents rms {rms:.3f}")
     assert e <= 2 * order and eh <= 2 * order_h
