@@ -80,9 +80,10 @@ class CausalFPSInferencePipeline(torch.nn.Module):
         # bit-identical).  False switches it off.
         self.share_block0 = True
         # The self-attention kernel's softmax is a max-free FAST pass per 256-row query block plus a GENERAL pass for the blocks it
-        # cannot hold (heavy-tailed scores: large QK-norm gains).  With a history (one byte per layer / head / block, kept with each
-        # branch's KV cache, zeroed per stage) a block that failed on the previous denoise step starts in GENERAL instead of paying for
-        # both.  Exact softmax either way; the bits then depend on the steps before (include/mmpl_hip.h).  False = stateless.
+        # cannot hold (heavy-tailed scores: large QK-norm gains).  With a history (a state byte + 128 lane references per layer / head /
+        # block, kept with each branch's KV cache, zeroed per stage) a block that failed takes its next FAST reference from what the last
+        # pass learned -- and, failing that too, starts in GENERAL -- instead of paying for both passes on every denoise step.  Exact
+        # softmax either way; for such blocks the bits then depend on the steps before (include/mmpl_hip.h).  False = stateless.
         self.attn_history = True
         self.cfg_pair = None              # mmpl_amd.handoff.CfgPair: this rank runs only the cond (role 0) / uncond (role 1) branch
 

@@ -1,9 +1,9 @@
 """The self-attention kernel's pass history (`attn_history`, include/mmpl_hip.h) and the MMPL_CHECK_SHARE guard (-m gpu).
 
 attn_w64_kernel runs a max-free FAST softmax pass per 256-row query block and redoes a block whose row sums left the window with
-the GENERAL pass.  With a history byte per block the failure of the previous launch sends the block straight to GENERAL; FAST is
-then run on the lane references the last pass left; a block that fails even so goes straight to GENERAL and FAST is
-retried on the 8th launch after that failure (then the 16th, then the 31st).  Checker: `oracle.sdpa_fp32` for every launch -- the
+the GENERAL pass.  With a history (a state byte + 128 lane references per block) a block that failed takes its next FAST reference from
+what the last pass learned; a block that fails even so goes straight to GENERAL and FAST is retried on the 8th launch after that
+failure (then the 16th, then the 31st).  Checker: `oracle.sdpa_fp32` for every launch -- the
 result is the exact softmax whichever pass ran -- plus the counters the kernel keeps.  Replaces attention.py:139-185 + the gather of
 causal_fps_model.py:219-227, as every attention test.
 """
