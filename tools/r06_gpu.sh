@@ -55,6 +55,12 @@ for spec in "$@"; do
       python bench.py --no-cpu-baseline --no-vae --heavy-tail --heavy-tail-gain 3 > $out/bench_14B_720p_heavy_tail_x3.json 2>> $out/bench.err; line $out/bench_14B_720p_heavy_tail_x3.json x3
       python bench.py --no-cpu-baseline --no-vae --heavy-tail > $out/bench_14B_720p_heavy_tail_x8.json 2>> $out/bench.err; line $out/bench_14B_720p_heavy_tail_x8.json x8
       python bench.py --no-cpu-baseline --no-vae --heavy-tail --heavy-tail-heads 0.15 > $out/bench_14B_720p_heavy_tail_x8_p15.json 2>> $out/bench.err; line $out/bench_14B_720p_heavy_tail_x8_p15.json "x8 p=0.15" ;;
+    htlong)      # heavy tail x8 over 40 timed steps (every stage replayed 12 times): the history's steady state, on / off
+      for h in "" "--no-attn-history"; do
+        python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-vae --heavy-tail $h > $out/htlong_tmp.json 2>> $out/bench.err; line $out/htlong_tmp.json "x8, 40 steps [$h]" >> $out/heavy_tail_x8_40_steps.log
+      done; cat $out/heavy_tail_x8_40_steps.log ;;
+    i2vmodel)
+      python bench.py $SHORT --i2v-model > $out/bench_i2v_model_type_14B_720p.json 2>> $out/bench.err; line $out/bench_i2v_model_type_14B_720p.json "Wan-I2V model type 14B/720p" ;;
     insitu)      # two PREBUILT libraries alternating in situ (tools/build/libmmpl_hip_{prev,new}.so): 14B / 720p --profile-all and 1.3B / 480p
       for v in prev new prev new; do
         cp tools/build/libmmpl_hip_$v.so mmpl_amd/lib/libmmpl_hip.so
