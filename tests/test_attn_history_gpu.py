@@ -108,6 +108,8 @@ def test_history_backs_off_blocks_that_fail_even_on_remembered_references(lib, s
     rows = torch.cat([torch.arange(0, 600), torch.arange(cs["Lq"] - 1200, cs["Lq"])])
     ref = _ref(cs, cs["kc"], rows)
     nz = lambda: sorted(set(_states(cs, hist)[_states(cs, hist) != 0].tolist()))
+    from oracle.attn_history_ref import next_state, plan       # the state byte's CPU restatement: a block with a spiked row fails whenever FAST runs
+    model = 0
 
     # stateless launch = the kernel of every earlier round: the reference bits for "FAST then GENERAL"
     o_stateless, st0 = _launch(lib, cs, cs["kc"], None, stats, ws)
@@ -117,7 +119,8 @@ def test_history_backs_off_blocks_that_fail_even_on_remembered_references(lib, s
     o1, st = _launch(lib, cs, cs["kc"], hist, stats, ws)
     assert st == st0 and torch.equal(o1, o_stateless)
     h = _states(cs, hist)
-    assert int((h != 0).sum()) == st[1] and nz() == [MEM]
+    model = next_state(model, True)
+    assert int((h != 0).sum()) == st[1] and nz() == [MEM] == [model]
     marked = {(int(a), int(b)) for a, b, _ in (h != 0).nonzero().tolist()}
     # row 300 (query block 1, main round) meets its key in KV tile 10, far outside the FAST reference's four-tile sample
     assert {a for a, _ in marked} == cs["hot_heads"] and all((hh, 1) in marked for hh in cs["hot_heads"]), marked
@@ -128,25 +131,33 @@ def test_history_backs_off_blocks_that_fail_even_on_remembered_references(lib, s
     o, st = _launch(lib, cs, cs["kc"], hist, stats, ws)
     assert st[1] + st[4] == redone and st[1] > 0 and st[3] == 0 and rel_l2(o[rows], ref) < 1e-2, st
     again, held = st[1], st[4]
-    assert nz() in ([MEM | 8], [MEM, MEM | 8])
+    model = next_state(model, True)
+    assert nz() in ([MEM | 8], [MEM, MEM | 8]) and model == MEM | 8
     # launches 3 .. 9: those blocks go straight to GENERAL (nothing is paid twice), the countdown runs 7 .. 1
     for n in range(3, 10):
         o, st = _launch(lib, cs, cs["kc"], hist, stats, ws)
         assert st[1] == 0 and st[3] == again and st[4] == held and st[0] == st0[0], (n, st)
         assert rel_l2(o[rows], ref) < 1e-2 and torch.isfinite(o.float()).all()
-        assert (MEM | (10 - n)) in nz()
+        assert plan(model) == (False, True)
+        model = next_state(model, True)
+        assert model == (MEM | (10 - n)) and model in nz()
     # launch 10: FAST is tried again, fails again, the interval doubles (level 1, countdown 16)
     o, st = _launch(lib, cs, cs["kc"], hist, stats, ws)
-    assert st[1] == again and st[3] == 0 and (MEM | (1 << 5) | 16) in nz() and rel_l2(o[rows], ref) < 1e-2
+    assert plan(model) == (True, True)
+    model = next_state(model, True)
+    assert st[1] == again and st[3] == 0 and model == (MEM | (1 << 5) | 16) and model in nz() and rel_l2(o[rows], ref) < 1e-2
     # ... 15 launches straight to GENERAL, and when FAST holds at the retry (calm keys now) the back-off clears
     ref_calm = _ref(cs, cs["kc_calm"], rows)
     for n in range(15):
         o, st = _launch(lib, cs, cs["kc_calm"], hist, stats, ws)
-        assert st[1] == 0 and st[3] == again
+        assert st[1] == 0 and st[3] == again and plan(model) == (False, True)
+        model = next_state(model, False)
+        assert model in nz()
         # (every launch: the 15th takes the countdown from 2 to 1 -- the value at which a wave that read the byte late would decide
         # differently from its block; the kernel rewrites the byte only after a barrier)
         assert rel_l2(o[rows], ref_calm) < 1e-2, n
     o, st = _launch(lib, cs, cs["kc_calm"], hist, stats, ws)
+    assert plan(model) == (True, True) and next_state(model, False) == MEM
     assert st[1] == 0 and st[3] == 0 and st[4] == redone and nz() == [MEM]
     assert rel_l2(o[rows], ref_calm) < 1e-2
     for r in (5, 300):                                                     # the spiked rows on the spiked keys: one-hot-like softmax, 2 bf16 ulps

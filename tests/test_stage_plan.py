@@ -110,3 +110,34 @@ def test_executed_flops_differ_from_algorithmic_only_where_launches_are_skipped(
     exe = sum(dit_forward_flops_executed(cfg, S, q, kv, 65) + dit_forward_flops_executed(cfg, S, q, kv, 65, block0_self_attn_shared=(q * S * d > 60e6))
               for q, kv in T2V_STAGE_SHAPES)
     assert 0.010 < 1 - exe / alg < 0.018, 1 - exe / alg
+
+
+def test_attention_history_state_machine():
+    """oracle/attn_history_ref.py restates the state byte of the self-attention kernel's pass history (include/mmpl_hip.h `attn_history`);
+    tests/test_attn_history_gpu.py holds the kernel's bytes to it launch by launch.  Here: its invariants over all 256 byte values."""
+    from oracle.attn_history_ref import MEM, next_state, passes_paid, plan
+    assert plan(0) == (True, False) and next_state(0, False) == 0              # a block that never fails never leaves 0
+    assert next_state(0, True) == MEM and plan(MEM) == (True, True)            # first failure: references, FAST again (on them)
+    for s in range(256):
+        try_fast, mem = plan(s)
+        for failed in (False, True):
+            n = next_state(s, failed)
+            assert 0 <= n < 256 and (n & MEM) >= (s & MEM) and ((n & MEM) or not (failed and try_fast))   # bit 7 is never cleared; a failed FAST pass sets it
+            assert ((n >> 5) & 3) <= 2 or not try_fast                                           # the level saturates at 2
+            if not try_fast:
+                assert n == s - 1 and (n & 31) == (s & 31) - 1 and passes_paid(s, failed) == 1.66
+            elif not failed:
+                assert n == (s & MEM) and passes_paid(s, failed) == 1.0
+    # a block that keeps failing even on remembered references: 8 launches to the first retry, 16 to the next, then 31
+    s, trace = 0, []
+    for launch in range(80):
+        tf, _ = plan(s)
+        trace.append("F" if tf else "g")
+        s = next_state(s, fast_failed=True)
+    assert "".join(trace) == "FF" + "g" * 7 + "F" + "g" * 15 + "F" + ("g" * 30 + "F") * 1 + "g" * 23, "".join(trace)
+    # ... and a heavy-tailed block whose remembered references hold: pays twice once, then one pass per launch, for ever
+    s, cost = 0, []
+    for launch, failed in enumerate([True] + [False] * 9):
+        cost.append(passes_paid(s, failed))
+        s = next_state(s, failed)
+    assert cost == [2.66] + [1.0] * 9 and s == MEM
