@@ -121,27 +121,36 @@ if fs:
         lines.append(f"| `{k[:70]}` | {cnt[k]} | {100 * a['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc):.1f} % | {cyc / dur[k]:.2f} | "
                      f"{a['SQ_WAVE_CYCLES'] * 4 / 1024 / cyc:.2f} |")
     open(os.path.join(d, f"{tag}_pmc_mfma_busy.md"), "w").write("\n".join(lines) + "\n")
-# ---- L2 (TCC) hits / misses and fabric reads per launch of the block GEMMs (tools/r06_gpu.sh tcc: bench_kernels.py gemm, one launch per shape)
-fs = glob.glob(os.path.join(d, "tcc_*", "**", "*counter_collection.csv"), recursive=True)
+# ---- L2 (TCC) hits / misses and fabric reads per launch of the block GEMMs (tools/r06_gpu.sh tcc: bench_kernels.py gemm, ONE shape per pass;
+# the pass directory is tcc_<shape>__<counters>; the persistent launch = one block per CU is the product's)
+fs = glob.glob(os.path.join(d, "tcc_*__*", "**", "*counter_collection.csv"), recursive=True)
 if fs:
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     nlaunch = collections.defaultdict(lambda: collections.defaultdict(set))
     for f in fs:
+        shape = re.search(r"tcc_([a-z0-9]+)__", f).group(1)
         for r in csv.DictReader(open(f)):
-            if "gemm_" not in r["Kernel_Name"]:
+            if "gemm_" not in r["Kernel_Name"] or int(r["Grid_Size"]) > 512 * 256:      # product launches only: one block per CU
                 continue
-            key = (short(r["Kernel_Name"])[:60], r["Grid_Size"])
+            key = (shape, short(r["Kernel_Name"])[:44])
             acc[key][r["Counter_Name"]] += float(r["Counter_Value"])
             nlaunch[key][r["Counter_Name"]].add(r["Dispatch_Id"])
-    lines = [f"# {tag} PMC: L2 (TCC) behaviour of the 14B / 720p block GEMMs, per launch", "",
-             "`rocprofv3 --kernel-trace --pmc <TCC_HIT_sum TCC_MISS_sum | TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum | FETCH_SIZE>` (separate passes) "
-             "`-- python3 tools/bench_kernels.py gemm --iters 1` (warm-up launches included in the mean); FETCH_SIZE bytes = KiB x 1024 x 2 on gfx950.", "",
-             "| kernel | grid | launches | L2 hits | L2 misses | hit rate | fabric read requests (32 B of them) | fabric read GB |", "|---|---|---|---|---|---|---|---|"]
-    for key in sorted(acc, key=lambda k: -acc[k].get("TCC_HIT_sum", 0)):
+    dims = {"qkv": (25200, 15360, 5120), "o": (25200, 5120, 5120), "cq": (25200, 5120, 5120), "co": (25200, 5120, 5120), "ffn0": (25200, 13824, 5120), "ffn2": (25200, 5120, 13824)}
+    lines = [f"# {tag} PMC: L2 (TCC) behaviour of the six 14B / 720p block GEMM shapes at M = 25 200, per launch", "",
+             "`rocprofv3 --kernel-trace --pmc <TCC_HIT_sum TCC_MISS_sum | TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum | FETCH_SIZE>` (separate passes, one shape per pass) "
+             "`-- python3 tools/bench_kernels.py gemm --iters 1`; the launches with one block per CU (tile tickets: what `mmpl_dit_forward` issues), mean over them; "
+             "FETCH_SIZE bytes = KiB x 1024 x 2 on gfx950.  Operands = (M + N) x K x 2 B; geometry = what 8 XCDs streaming the 4 activation + 8 weight panels of a "
+             "4 x 8 tile arrangement once per round of 32 tiles would fetch with perfect sharing inside each L2.", "",
+             "| shape (M x N x K) | kernel | launches | L2 hits | L2 misses | hit rate | fabric read requests | fabric read GB | operands GB | geometry GB |", "|---|---|---|---|---|---|---|---|---|---|"]
+    for key in sorted(acc):
         a = acc[key]
         per = lambda c: a[c] / max(len(nlaunch[key][c]), 1) if c in a else float("nan")
         hit, miss = per("TCC_HIT_sum"), per("TCC_MISS_sum")
-        lines.append(f"| `{key[0]}` | {key[1]} | {max((len(v) for v in nlaunch[key].values()), default=0)} | {hit:.4g} | {miss:.4g} | "
-                     f"{100 * hit / max(hit + miss, 1):.1f} % | {per('TCC_EA0_RDREQ_sum'):.4g} ({per('TCC_EA0_RDREQ_32B_sum'):.4g}) | {per('FETCH_SIZE') * 2048 / 1e9:.3f} |")
+        M, N, K = dims.get(key[0], (0, 0, 0))
+        ops = (M + N) * K * 2 / 1e9
+        tiles = -(-M // 256) * -(-N // 256)
+        geo = tiles / 32.0 * 12 * 256 * K * 2 / 1e9
+        lines.append(f"| {key[0]} {M} x {N} x {K} | `{key[1]}` | {max((len(v) for v in nlaunch[key].values()), default=0)} | {hit:.4g} | {miss:.4g} | "
+                     f"{100 * hit / max(hit + miss, 1):.1f} % | {per('TCC_EA0_RDREQ_sum'):.4g} | {per('FETCH_SIZE') * 2048 / 1e9:.3f} | {ops:.3f} | {geo:.2f} |")
     open(os.path.join(d, f"{tag}_pmc_gemm_l2.md"), "w").write("\n".join(lines) + "\n")
 print("post-processing done:", sorted(os.path.basename(p) for p in glob.glob(os.path.join(d, f"{tag}_*"))))

@@ -85,10 +85,13 @@ for spec in "$@"; do
       done; build ""; cat $out/devflags.log ;;
     gemmphases)  # { prologue, k loop, epilogue } shader cycles of the large GEMM kernels (a -DGEMM6_TIMING=1 development build)
       build "-DMMPL_DEV_ABLATIONS -DGEMM6_TIMING=1 $arg"; timeout 300 python tools/bench_kernels.py gemmphases 2>&1 | grep gemmphases > $out/gemm_phases.log; build ""; cat $out/gemm_phases.log ;;
-    tcc)         # L2 hit / miss and fabric read bytes of the six block GEMM shapes (item 4: how much of the fabric traffic is geometry?)
-      for pmc in "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "FETCH_SIZE"; do
-        t=$(echo $pmc | tr ' ' '_')
-        BENCH_SHAPES=$BIG timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $pmc -d $out/tcc_$t -o p -- python3 tools/bench_kernels.py gemm --iters 1 > /dev/null 2> $out/tcc_$t.err
+    tcc)         # L2 hit / miss and fabric read bytes of the six block GEMM shapes, one shape per pass (item 4: how much of the fabric traffic is geometry?)
+      for shp in qkv:25200:15360:5120:0 o:25200:5120:5120:3 cq:25200:5120:5120:0 co:25200:5120:5120:4 ffn0:25200:13824:5120:1 ffn2:25200:5120:13824:3; do
+        name=${shp%%:*}
+        for pmc in "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "FETCH_SIZE"; do
+          t=$(echo $pmc | tr ' ' '_')
+          BENCH_SHAPES=$shp timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc $pmc -d $out/tcc_${name}__$t -o p -- python3 tools/bench_kernels.py gemm --iters 1 > /dev/null 2> $out/tcc_${name}__$t.err
+        done
       done
       python3 tools/profiles_post.py $out $tag tcc; cat $out/${tag}_pmc_gemm_l2.md ;;
     stats)       # rocprofv3 kernel stats of the bench command itself
