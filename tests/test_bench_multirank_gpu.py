@@ -151,3 +151,32 @@ def test_default_eight_rank_line_is_four_lanes_of_cfg_pairs():
     assert all(st >= a - 0.05 for st, a in zip(r["stagger_s"], r["anchor_done_after_s"]))
     k = r["config"]["sampling_steps"]
     assert abs(r["wall_scale_to_50_steps"] - _scale_to_50(k, 8)) < 1e-9 and r["value"] > 0
+
+
+def test_single_gpu_bench_line_fields_and_heavy_tail_switches():
+    """One rank, small model: the default line's contract fields (BASELINE metric, `roofline`, executed vs algorithmic PFLOP/s) and the
+    diagnostic switches of the self-attention's pass history (`--heavy-tail [--heavy-tail-heads P]`, `--no-attn-history`): the counters
+    add up, and without the history nothing is predicted or remembered."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--model", "small", "--res", "tiny", "--steps", "12", "--warmup", "4", "--no-cpu-baseline", "--no-vae",
+            "--probe-seconds", "0"]
+
+    def run(extra):
+        p = subprocess.run(base + extra, env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, p.stdout[-2000:]
+        return json.loads(lines[0])
+
+    r = run([])
+    assert r["metric"] == "video_latent_frames_per_sec" and r["n_gpus"] == 1 and r["dtype"] == "bf16" and r["vs_baseline"] is None
+    assert r["roofline"]["bound"] == "mfma" and r["roofline"]["achieved"] > 0 and "attn_history" in r and r["attn_history"].startswith("on")
+    assert 0 < r["executed_pflops_per_gpu"] <= r["achieved_pflops_per_gpu"] and "flop_accounting" in r
+    assert "attn_blocks" not in r                                        # counters only under --attn-stats / --heavy-tail
+    h = run(["--heavy-tail", "--heavy-tail-gain", "12", "--heavy-tail-heads", "0.5"])
+    assert "0.5 of every layer's heads" in h["weights"] and h["attn_blocks"] > 0
+    parts = h["attn_blocks_redone"] + h["attn_blocks_predicted"] + h["attn_blocks_fast_on_remembered_reference"]
+    assert 0 <= parts <= h["attn_blocks"] and h["attn_blocks_redone_fraction"] == h["attn_blocks_redone"] / h["attn_blocks"]
+    n = run(["--heavy-tail", "--heavy-tail-gain", "12", "--heavy-tail-heads", "0.5", "--no-attn-history"])
+    assert n["attn_history"].startswith("off") and n["attn_blocks_predicted"] == 0 and n["attn_blocks_fast_on_remembered_reference"] == 0
+    assert n["attn_blocks_redone"] >= h["attn_blocks_redone"]           # with the history a failing block does not keep paying twice
