@@ -171,3 +171,27 @@ def test_concurrent_cfg_branches_are_bit_identical_to_sequential():
     _, b = pipe.inference(noise.cuda(), ["a cat"], initial_latent=init.cuda(), return_latents=True, decode=False)
     torch.cuda.synchronize()
     assert torch.equal(a, res[False][0]) and torch.equal(b, res[False][1])
+
+
+def test_attention_history_changes_nothing_where_no_block_fails():
+    """`pipeline.attn_history` (default True): each CFG branch's KV cache carries the self-attention's pass history from step to step.
+    A block whose FAST pass never fails never leaves the zero state, i.e. computes the stateless kernel's bits -- so on weights whose
+    scores the FAST pass holds (these) a whole chunk, first and later, is bit-identical with and without it; and the history stays zero."""
+    from mmpl_amd.synthetic import philox_normal
+    pipe, *_ = _setup("t2v", steps=3)
+    noise = philox_normal([1, 21, 16, *LAT], 23)
+    renoise = {f: philox_normal([1, 16, *LAT], 100 + f) for f in (4, 9, 13, 18)}
+    pipe.renoise_override = {k: v.cuda() for k, v in renoise.items()}
+    init = philox_normal([1, 2, 16, *LAT], 55)
+    res = {}
+    for on in (True, False):
+        pipe.attn_history = on
+        _, a = pipe.inference(noise.cuda(), ["a cat"], return_latents=True, decode=False)
+        _, b = pipe.inference(noise.cuda(), ["a cat"], initial_latent=init.cuda(), return_latents=True, decode=False)
+        torch.cuda.synchronize()
+        res[on] = (a.clone(), b.clone())
+        for kv in (pipe.kv_cache_pos, pipe.kv_cache_neg):
+            assert (kv.attn_history is not None) == on
+            if on:
+                assert int(kv.attn_history.max()) == 0
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
