@@ -1224,13 +1224,16 @@ hipError_t launch_v6(const GemmArgs& g, hipStream_t s) {
   GemmArgs g2 = g;
   const MmplRuntimeConfig& rc = mmpl_config();
   const int env_group = rc.gemm_group;
-  // M-tile group of the block order (how many row panels the tiles in flight on an XCD span).  Sweeps with the sweep-synchronous
-  // order, nt stores and tile tickets on the 14B / 720p block shapes (TFLOP/s at group 2 / 3 / 4 / 8; profiles/r03d_*, r03C_*):
-  //   M = 25200 (99 row panels): qkv 1418 / 1431 / 1425 / 1397, ffn0 1351 / 1360 / 1379 / 1338, o 1294 / 1336 / 1307 / 1317, ffn2 1320 / 1312 / 1307 / 1313
-  //   M = 21600 (85 row panels): qkv 1372 / 1394 / 1413, ffn0 1298 / 1329 / 1321, o 1271 / 1284 / 1301, ffn2 1321 / 1312 / 1365
-  // -> 4, except the narrow (N < 8192) GEMMs when the row panels divide into groups of 3: 3, or 2 for the long-K one.
+  // M-tile group of the block order (how many row panels the tiles in flight on an XCD span).  Round 3 swept it on the kernels of the
+  // time (profiles/r03d_*, r03C_*) and gave the narrow (N < 8192) GEMMs groups of 3 (2 for the long-K one) where the row panels divide
+  // by 3; re-swept in round 6 on today's kernels (staged epilogue in phases, split-K tail; profiles/r06w_gemm_group_sweep_v6_shapes.log,
+  // TFLOP/s at group 2 / 3 / 4 / 6 / 8, one box):
+  //   M = 25200 (99 row panels): o 1289 / 1301 / 1333 / 1310 / 1362, cross-o 1317 / 1316 / 1355 / 1338 / 1373, ffn2 1363 / 1353 / 1401 / 1360 / 1392
+  //   M = 21600 (85 row panels): o 1293 / 1307 / 1331 / 1310 / 1326, ffn2 1344 / 1345 / 1396 / 1350 / 1388
+  // -> 4 (also what the wide GEMMs on v8 keep: profiles/r05g_gemm_group_sweep.log), except the narrow short-K GEMMs (o, cross-q,
+  // cross-o) of the 7-frame stage (>= 96 row panels): 8.
   const int tiles_m_ = (g.M + BM3 - 1) / BM3;
-  g2.group = env_group > 0 ? env_group : ((g.M >= 16384 && g.N < 8192 && tiles_m_ % 3 == 0) ? (g.K >= 8192 ? 2 : 3) : 4);
+  g2.group = env_group > 0 ? env_group : ((tiles_m_ >= 96 && g.N < 8192 && g.K < 8192) ? 8 : 4);
   // the 16-byte epilogue needs 8-element alignment of everything it touches; otherwise the direct 8-byte one
   // (strides AND base pointers: mmpl_gemm is public ABI and callers hand in views such as a column-offset C)
   auto al = [](const void* p, uintptr_t a) { return p == nullptr || reinterpret_cast<uintptr_t>(p) % a == 0; };
